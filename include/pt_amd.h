@@ -1,0 +1,302 @@
+/*
+ * pt_amd.h — C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * This library replaces the GPU pass of the Bevy plugin PixelDoted/path-tracing:
+ * the render pass that `RayTraceNode::run` records (reference src/shader.rs:121-213)
+ * and the shader it runs (src/raytrace.wgsl, src/query.wgsl, src/math.wgsl).
+ * Everything on the Rust side above that call (src/lib.rs, src/extract.rs,
+ * src/data.rs) keeps producing the same buffers; they are handed to the functions
+ * below instead of `StorageBuffer::write_buffer`.
+ *
+ * Conventions
+ *  - Every function returns 0 (PT_OK) or a negative PT_ERR_* code and never
+ *    throws or aborts across the boundary. `pt_last_error(ctx)` returns a
+ *    message owned by the context (valid until the next call on that context).
+ *  - Host pointers are borrowed for the duration of the call only.
+ *  - Matrices are column-major float[16] (glam `Mat4`, WGSL `mat4x4<f32>`).
+ *  - One caller thread per context. Calls on one context are serialised by the
+ *    caller; several contexts (one per GPU) may be driven from several threads.
+ *  - The struct layouts are the encase/std430 layouts of reference
+ *    src/data.rs:15-73 and are checked by static assertions.
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+/* ---- error codes --------------------------------------------------------- */
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = -1, /* null pointer, bad size, bad enum            */
+    PT_ERR_INVALID_SCENE = -2,    /* index out of range, non-finite geometry     */
+    PT_ERR_NOT_READY = -3,        /* render/query before the scene was uploaded  */
+    PT_ERR_DEVICE = -4,           /* HIP runtime error (message has the detail)  */
+    PT_ERR_OUT_OF_MEMORY = -5,
+    PT_ERR_UNSUPPORTED = -6,
+    PT_ERR_NO_DEVICE = -7         /* no gfx950 device / device index out of range */
+};
+
+/* "no texture" / "miss" marker (reference src/math.wgsl:5, src/extract.rs:235) */
+#define PT_U32_MAX 0xFFFFFFFFu
+
+/* ---- wire structs: byte-identical to the reference's storage buffers ------ */
+
+/* reference src/data.rs:23-30 == src/query.wgsl:16-22; stride 144 */
+typedef struct PtObject {
+    float local_to_world[16];
+    float world_to_local[16];
+    uint32_t mat;
+    uint32_t mesh;
+    uint32_t _pad[2];
+} PtObject;
+
+/* reference src/data.rs:58-66 == src/query.wgsl:24-31; stride 48 */
+typedef struct PtMesh {
+    float aabb_min[3];
+    uint32_t _pad0;
+    float aabb_max[3];
+    uint32_t ihead;     /* first element of this mesh in indices[]            */
+    uint32_t vhead;     /* first element of this mesh in vertices[]           */
+    uint32_t tri_count;
+    uint32_t _pad1[2];
+} PtMesh;
+
+/* reference src/data.rs:68-73 == src/query.wgsl:33-37; stride 48 */
+typedef struct PtVertex {
+    float position[3];
+    uint32_t _pad0;
+    float normal[3];
+    uint32_t _pad1;
+    float uv[2];
+    uint32_t _pad2[2];
+} PtVertex;
+
+/* reference src/data.rs:32-43 == src/raytrace.wgsl:29-39; stride 64 */
+typedef struct PtMaterial {
+    float albedo[3];
+    uint32_t albedo_texture;
+    float emissive[3];
+    uint32_t emissive_texture;
+    float roughness;
+    float metallic;
+    uint32_t metallic_roughness_texture;
+    float reflectance;
+    uint32_t normal_map_texture;
+    uint32_t _pad[3];
+} PtMaterial;
+
+/* reference src/data.rs:45-51 == src/raytrace.wgsl:41-46; stride 16.
+ * `offset` counts f32 elements of texture_data[]; `format` = channels/texel. */
+typedef struct PtTexture {
+    uint32_t width;
+    uint32_t height;
+    uint32_t offset;
+    uint32_t format;
+} PtTexture;
+
+/* reference src/data.rs:15-20 == src/raytrace.wgsl:23-27; size 32 */
+typedef struct PtSettings {
+    uint32_t bounces;
+    uint32_t samples;
+    uint32_t _pad[2];
+    float sky_color[4]; /* LinearRgba on the Rust side; the path reads xyz      */
+} PtSettings;
+
+/* ---- per-frame parameters ------------------------------------------------- */
+
+/* pt_render flags */
+#define PT_FRAME_ACCUMULATE 0x1u /* add this frame into the context's radiance
+                                    accumulation buffer and return the mean   */
+#define PT_FRAME_RESET      0x2u /* clear the accumulation buffer first        */
+
+/*
+ * The subset of Bevy's `View` and `Globals` uniforms the shader reads
+ * (reference src/raytrace.wgsl:210-217) plus the `Settings` uniform (:13).
+ * `width`/`height` are `view.viewport.zw`.
+ *
+ * Pixel partition (for multi-GPU tile splitting): the image is cut into 8x8
+ * pixel tiles numbered row-major; this call renders tile k iff
+ * k % part_count == part_index. part_count == 0 or 1 renders everything.
+ * Pixels outside the partition are written as zeros.
+ */
+typedef struct PtFrame {
+    float world_from_view[16];
+    float view_from_clip[16];
+    uint32_t width;
+    uint32_t height;
+    float time;          /* Globals.time, seconds                             */
+    uint32_t flags;      /* PT_FRAME_*                                         */
+    PtSettings settings;
+    uint32_t part_index;
+    uint32_t part_count;
+    uint32_t _reserved[2];
+} PtFrame;
+
+/* ---- context --------------------------------------------------------------- */
+
+/* closest-hit strategy */
+enum {
+    PT_ACCEL_AUTO = 0,  /* two-level LBVH where it pays, uniform loops otherwise */
+    PT_ACCEL_BRUTE = 1, /* the reference's loop nest (src/query.wgsl:55-125)     */
+    PT_ACCEL_BVH = 2    /* force TLAS + BLAS everywhere                          */
+};
+
+/* tie rule for exactly equal hit distances */
+enum {
+    PT_TIE_REFERENCE = 0, /* highest (object, triangle) wins — what the
+                             reference's `t > hit_record.t` reject test does
+                             (src/query.wgsl:109, :55-64)                       */
+    PT_TIE_LOWEST = 1     /* lowest (object, triangle) wins                     */
+};
+
+typedef struct PtConfig {
+    uint32_t abi_version; /* PT_ABI_VERSION                                    */
+    int32_t device;       /* HIP device ordinal                                */
+    uint32_t accel;       /* PT_ACCEL_*                                        */
+    uint32_t tie_rule;    /* PT_TIE_*                                          */
+    uint32_t flags;       /* reserved, 0                                       */
+    uint32_t _reserved[3];
+} PtConfig;
+
+typedef struct pt_ctx pt_ctx;
+
+/* Replaces RayTracePlugin::build/finish + RayTracePipeline::from_world
+ * (reference src/shader.rs:38-103, :225-339): creates the device state. */
+int pt_create(const PtConfig* cfg, pt_ctx** out_ctx);
+int pt_destroy(pt_ctx* ctx);
+
+/* Message for the most recent error on this context ("" if none).
+ * With ctx == NULL returns the message of the last failed pt_create. */
+const char* pt_last_error(const pt_ctx* ctx);
+
+/* ---- scene upload ---------------------------------------------------------- */
+
+/* Replaces the three `write_buffer` calls of prepare_meshes
+ * (reference src/extract.rs:131-144). Validates ranges, builds the per-mesh
+ * triangle records and BLAS on the device. Zero counts are legal. */
+int pt_upload_meshes(pt_ctx* ctx,
+                     const PtMesh* meshes, uint32_t n_meshes,
+                     const uint32_t* indices, uint32_t n_indices,
+                     const PtVertex* vertices, uint32_t n_vertices);
+
+/* Replaces the `write_buffer` calls of extract_materials / extract_textures
+ * (reference src/extract.rs:249-253, :284-292). */
+int pt_upload_materials(pt_ctx* ctx,
+                        const PtMaterial* materials, uint32_t n_materials,
+                        const PtTexture* textures, uint32_t n_textures,
+                        const float* texture_data, uint32_t n_texture_data);
+
+/* Replaces the per-frame `objects.write_buffer` of extract_visible
+ * (reference src/extract.rs:337-342); rebuilds the TLAS. The reference's
+ * `emissives` buffer is bound but never read by the shader and is not taken. */
+int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects);
+
+/* ---- render ---------------------------------------------------------------- */
+
+/* Replaces the body of RayTraceNode::run (reference src/shader.rs:121-213):
+ * traces the frame and copies width*height RGBA f32 (row 0 = top, A = 1) to
+ * `out_rgba_host`. Synchronous. */
+int pt_render(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_host);
+
+/* Same, but the image is written to device memory of the context's device and
+ * the call returns after enqueueing on `hip_stream` (a hipStream_t, or NULL for
+ * the context's own stream, in which case the call synchronises before
+ * returning). Used by callers that keep the image on the GPU (multi-GPU
+ * reduce/gather, on-device post-processing). */
+int pt_render_device(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_device,
+                     void* hip_stream);
+
+/* ---- closest-hit query (the query.wgsl entry point on its own) -------------- */
+
+typedef struct PtRay {
+    float pos[3];
+    float dir[3];
+} PtRay;
+
+/* What `hit_all` returns plus the `hit_record` side channel
+ * (reference src/query.wgsl:45-64), plus the winning triangle. */
+typedef struct PtHit {
+    uint32_t object;   /* PT_U32_MAX on miss                                    */
+    uint32_t triangle; /* triangle index inside the object's mesh               */
+    uint32_t flat_id;  /* triangle id in the order of the reference's double
+                          loop (objects outer, triangles inner)                 */
+    float t;
+    float p[3];
+    float n[3];
+    float uv[2];
+} PtHit;
+
+/* hit_all(ray) for n host rays (reference src/query.wgsl:55-64 with
+ * hit_record.t preset to 1000.0 as at src/raytrace.wgsl:230). */
+int pt_query(pt_ctx* ctx, const PtRay* rays_host, uint32_t n_rays, PtHit* hits_host);
+
+/* ---- auxiliary read-back ---------------------------------------------------- */
+
+enum {
+    PT_AUX_PRIMARY_OBJECT = 0, /* u32[W*H]  object id of the primary hit        */
+    PT_AUX_PRIMARY_FLAT_ID = 1,/* u32[W*H]  flat triangle id of the primary hit */
+    PT_AUX_PRIMARY_T = 2,      /* f32[W*H]  its distance (1000.0 on miss)       */
+    PT_AUX_RAY_COUNT = 3       /* u32[W*H]  closest-hit queries traced per pixel*/
+};
+/* Valid after a pt_render / pt_render_device of the same size. */
+int pt_read_aux(pt_ctx* ctx, uint32_t kind, void* out_host, size_t out_bytes);
+
+/* Work counters of the most recent render on this context. */
+typedef struct PtStats {
+    uint64_t rays;          /* closest-hit queries executed                     */
+    uint64_t rays_reference;/* queries the reference would run for the same
+                               image (it re-traces the identical primary ray
+                               for every sample, src/raytrace.wgsl:223)          */
+    uint64_t paths;         /* pixels * samples                                 */
+    uint64_t xforms;        /* ray-object transforms + gate tests               */
+    uint64_t box_tests;     /* BVH node-child box tests                          */
+    uint64_t tri_tests;     /* ray-triangle tests                               */
+    uint64_t shades;        /* scatter evaluations (calculate_brdf)             */
+    double trace_ms;        /* device time of the trace kernel(s), HIP events   */
+    double build_ms;        /* device time of the last TLAS build                */
+    uint32_t trace_launches;/* kernel launches that trace_ms covers              */
+    uint32_t accel_used;    /* bit 0: TLAS traversal, bit 1: BLAS traversal      */
+} PtStats;
+
+/* detail != 0 re-runs nothing; it only selects whether the next renders also
+ * gather xforms/box_tests/tri_tests/shades (slower kernel variant). */
+int pt_set_stats_detail(pt_ctx* ctx, int detail);
+int pt_get_stats(pt_ctx* ctx, PtStats* out);
+
+/* Library / device description, for logs. */
+int pt_device_info(pt_ctx* ctx, char* buf, size_t buf_bytes);
+
+/* Diagnostics: verifies on the device that every node box of the TLAS and of every
+ * BLAS encloses what lies below it; *n_errors = number of violations found.
+ * Also reports the tree depths (in nodes) when the pointers are not NULL. */
+int pt_debug_check_accel(pt_ctx* ctx, uint32_t* n_errors, uint32_t* tlas_depth, uint32_t* max_blas_depth);
+
+#ifdef __cplusplus
+} /* extern "C" */
+
+static_assert(sizeof(PtObject) == 144, "Object stride (src/data.rs:23-30)");
+static_assert(offsetof(PtObject, world_to_local) == 64, "Object.world_to_local");
+static_assert(offsetof(PtObject, mat) == 128 && offsetof(PtObject, mesh) == 132, "Object.mat/mesh");
+static_assert(sizeof(PtMesh) == 48, "GpuMesh stride (src/data.rs:58-66)");
+static_assert(offsetof(PtMesh, aabb_max) == 16 && offsetof(PtMesh, ihead) == 28 &&
+              offsetof(PtMesh, vhead) == 32 && offsetof(PtMesh, tri_count) == 36, "GpuMesh offsets");
+static_assert(sizeof(PtVertex) == 48, "GpuVertex stride (src/data.rs:68-73)");
+static_assert(offsetof(PtVertex, normal) == 16 && offsetof(PtVertex, uv) == 32, "GpuVertex offsets");
+static_assert(sizeof(PtMaterial) == 64, "Material stride (src/data.rs:32-43)");
+static_assert(offsetof(PtMaterial, albedo_texture) == 12 && offsetof(PtMaterial, emissive) == 16 &&
+              offsetof(PtMaterial, emissive_texture) == 28 && offsetof(PtMaterial, roughness) == 32 &&
+              offsetof(PtMaterial, metallic) == 36 && offsetof(PtMaterial, metallic_roughness_texture) == 40 &&
+              offsetof(PtMaterial, reflectance) == 44 && offsetof(PtMaterial, normal_map_texture) == 48,
+              "Material offsets");
+static_assert(sizeof(PtTexture) == 16, "Texture stride (src/data.rs:45-51)");
+static_assert(sizeof(PtSettings) == 32 && offsetof(PtSettings, sky_color) == 16, "Settings (src/data.rs:15-20)");
+#endif
+
+#endif /* PT_AMD_H */

@@ -1,0 +1,770 @@
+// pt_amd.hip — context, scene upload and the C ABI of include/pt_amd.h.
+// Single translation unit for gfx950: hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+#include "pt_build.h"
+#include "pt_trace.h"
+
+static_assert(sizeof(DMaterial) == sizeof(PtMaterial) && sizeof(DTexture) == sizeof(PtTexture), "wire == device");
+static_assert(sizeof(WObject) == sizeof(PtObject) && sizeof(WMesh) == sizeof(PtMesh) && sizeof(WVertex) == sizeof(PtVertex), "wire");
+static_assert(sizeof(DRay) == sizeof(PtRay) && sizeof(DHit) == sizeof(PtHit), "query structs");
+
+namespace {
+
+constexpr uint32_t kBlasMinTris = 8;    // PT_ACCEL_AUTO: meshes with more triangles than this get a BLAS
+constexpr uint32_t kTlasMinObjects = 12; // PT_ACCEL_AUTO: scenes with more objects than this get a TLAS
+constexpr uint32_t kMaxStackDepth = 96;  // LDS: 4 waves * depth * 256 B per workgroup
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max<size_t>(bytes, 256);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct pt_ctx {
+    PtConfig cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evb0 = nullptr, evb1 = nullptr;
+    std::string err;
+    char info[256] = {0};
+
+    // uploaded wire arrays (device copies)
+    DevBuf w_meshes, w_indices, w_vertices, w_objects;
+    // traversal layout
+    DevBuf d_meshes, d_tris, d_attrs, d_tri_lo, d_tri_hi, d_blas_nodes;
+    DevBuf d_objects, d_obj_lo, d_obj_hi, d_tlas_nodes, d_tri_base;
+    DevBuf d_materials, d_textures, d_texdata;
+    // scratch for uploads / builds
+    DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
+        t_bounds, t_info, t_errors;
+    // frame outputs
+    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits;
+
+    std::vector<DMesh> h_meshes;
+    std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
+    uint32_t n_meshes = 0, n_tris = 0, n_objects = 0, n_materials = 0, n_textures = 0, n_texdata = 0;
+    uint32_t n_blas_nodes = 0;
+    uint32_t obj_max_mesh = 0, obj_max_mat = 0;
+    uint32_t max_blas_depth = 0, tlas_depth = 0, tlas_root = PT_NONE;
+    bool have_meshes = false, have_materials = false, have_objects = false;
+    bool use_tlas = false;
+    std::vector<PtObject> h_objects;  // kept so that a mesh re-upload can rebuild the instance data
+
+    uint32_t aux_w = 0, aux_h = 0;
+    uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
+    bool stats_detail = false;
+    bool timing_pending = false;
+    PtStats stats{};
+    uint64_t last_paths = 0, last_primary = 0;
+};
+
+namespace {
+
+int fail(pt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define PT_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e__ = (call);                                                                            \
+        if (e__ != hipSuccess) {                                                                            \
+            int code__ = (e__ == hipErrorOutOfMemory) ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE;               \
+            return fail(ctx, code__, std::string(#call) + ": " + hipGetErrorString(e__));                   \
+        }                                                                                                   \
+    } while (0)
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+inline bool finite3(const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+
+// ---- LBVH over n boxes box_lo/hi[first .. first+n) -> nodes[0 .. n-1) ----------------------
+// Child references to internal nodes are node_base + index; depth goes to info_slot (device).
+int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t first, uint32_t n, BvhNode* nodes,
+               uint32_t node_base, uint32_t* info_slot) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n_blocks = div_up(n, RS_KEYS);
+    PT_HIP(ctx, ctx->t_keys0.ensure(sizeof(uint32_t) * n));
+    PT_HIP(ctx, ctx->t_keys1.ensure(sizeof(uint32_t) * n));
+    PT_HIP(ctx, ctx->t_vals0.ensure(sizeof(uint32_t) * n));
+    PT_HIP(ctx, ctx->t_vals1.ensure(sizeof(uint32_t) * n));
+    PT_HIP(ctx, ctx->t_hist.ensure(sizeof(uint32_t) * 256 * n_blocks));
+    PT_HIP(ctx, ctx->t_par_int.ensure(sizeof(uint32_t) * n));
+    PT_HIP(ctx, ctx->t_par_leaf.ensure(sizeof(uint32_t) * n));
+    PT_HIP(ctx, ctx->t_arrive.ensure(sizeof(uint32_t) * n));
+    PT_HIP(ctx, ctx->t_bounds.ensure(sizeof(uint32_t) * 8));
+
+    uint32_t* bounds = ctx->t_bounds.as<uint32_t>();
+    PT_HIP(ctx, hipMemsetAsync(bounds, 0xFF, 12, s));
+    PT_HIP(ctx, hipMemsetAsync(bounds + 3, 0x00, 12, s));
+    k_centroid_bounds<<<div_up(n, 256), 256, 0, s>>>(box_lo, box_hi, first, n, bounds);
+    uint32_t *k0 = ctx->t_keys0.as<uint32_t>(), *k1 = ctx->t_keys1.as<uint32_t>();
+    uint32_t *v0 = ctx->t_vals0.as<uint32_t>(), *v1 = ctx->t_vals1.as<uint32_t>();
+    k_morton<<<div_up(n, 256), 256, 0, s>>>(box_lo, box_hi, first, n, bounds, k0, v0);
+    uint32_t* hist = ctx->t_hist.as<uint32_t>();
+    for (uint32_t shift = 0; shift < 32; shift += 8) {
+        k_rs_hist<<<n_blocks, 64, 0, s>>>(k0, n, shift, n_blocks, hist);
+        k_rs_scan<<<1, 1024, 0, s>>>(hist, 256 * n_blocks);
+        k_rs_scatter<<<n_blocks, 64, 0, s>>>(k0, v0, k1, v1, n, shift, n_blocks, hist);
+        std::swap(k0, k1);
+        std::swap(v0, v1);
+    }
+    // after 4 passes the sorted data is back in t_keys0 / t_vals0
+    uint32_t* par_int = ctx->t_par_int.as<uint32_t>();
+    uint32_t* par_leaf = ctx->t_par_leaf.as<uint32_t>();
+    uint32_t* arrive = ctx->t_arrive.as<uint32_t>();
+    PT_HIP(ctx, hipMemsetAsync(arrive, 0, sizeof(uint32_t) * n, s));
+    k_karras<<<div_up(n - 1, 256), 256, 0, s>>>(k0, n, par_int, par_leaf);
+    k_fit<<<div_up(n, 256), 256, 0, s>>>(box_lo, box_hi, first, v0, n, par_int, par_leaf, arrive, nodes, node_base, info_slot);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int rebuild_objects(pt_ctx* ctx);
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
+    try {
+        if (!cfg || !out_ctx) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "pt_create: null argument");
+        *out_ctx = nullptr;
+        if (cfg->abi_version != PT_ABI_VERSION) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "pt_create: abi_version mismatch");
+        if (cfg->accel > PT_ACCEL_BVH || cfg->tie_rule > PT_TIE_LOWEST) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "pt_create: bad accel/tie_rule");
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: no HIP device");
+        if (cfg->device < 0 || cfg->device >= n_dev) return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: device ordinal out of range");
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, PT_ERR_DEVICE, "pt_create: hipGetDeviceProperties failed");
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(nullptr, PT_ERR_NO_DEVICE, std::string("pt_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        pt_ctx* ctx = new pt_ctx();
+        ctx->cfg = *cfg;
+        ctx->device = cfg->device;
+        std::snprintf(ctx->info, sizeof ctx->info, "pt_amd abi %d | %s %s | %d CUs | %d MHz | %.0f GiB", PT_ABI_VERSION, prop.name,
+                      prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1073741824.0);
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->evb0);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->evb1);
+        if (e == hipSuccess) e = ctx->d_counters.ensure(sizeof(DCounters));
+        if (e != hipSuccess) {
+            std::string m = std::string("pt_create: ") + hipGetErrorString(e);
+            pt_destroy(ctx);
+            return fail(nullptr, PT_ERR_DEVICE, m);
+        }
+        *out_ctx = ctx;
+        return PT_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(nullptr, PT_ERR_OUT_OF_MEMORY, "pt_create: host allocation failed");
+    } catch (...) {
+        return fail(nullptr, PT_ERR_DEVICE, "pt_create: unexpected exception");
+    }
+}
+
+int pt_destroy(pt_ctx* ctx) {
+    if (!ctx) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->w_meshes, &ctx->w_indices, &ctx->w_vertices, &ctx->w_objects, &ctx->d_meshes, &ctx->d_tris,
+                      &ctx->d_attrs, &ctx->d_tri_lo, &ctx->d_tri_hi, &ctx->d_blas_nodes, &ctx->d_objects, &ctx->d_obj_lo,
+                      &ctx->d_obj_hi, &ctx->d_tlas_nodes, &ctx->d_tri_base, &ctx->d_materials, &ctx->d_textures,
+                      &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
+                      &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
+                      &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
+                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evb0) (void)hipEventDestroy(ctx->evb0);
+    if (ctx->evb1) (void)hipEventDestroy(ctx->evb1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PT_OK;
+}
+
+int pt_device_info(pt_ctx* ctx, char* buf, size_t buf_bytes) {
+    if (!ctx || !buf || buf_bytes == 0) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_device_info: null argument");
+    std::snprintf(buf, buf_bytes, "%s", ctx->info);
+    return PT_OK;
+}
+
+// ---- meshes ---------------------------------------------------------------------------------
+int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const uint32_t* indices, uint32_t n_indices,
+                     const PtVertex* vertices, uint32_t n_vertices) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if ((n_meshes && !meshes) || (n_indices && !indices) || (n_vertices && !vertices))
+            return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_meshes: null array with non-zero count");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        // validate (the shader would read out of bounds; here it is an error)
+        uint64_t total_tris = 0;
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            const PtMesh& me = meshes[m];
+            if ((uint64_t)me.ihead + 3ull * me.tri_count > n_indices)
+                return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_meshes: mesh " + std::to_string(m) + " index range exceeds indices[]");
+            for (uint32_t i = 0; i < 3u * me.tri_count; ++i)
+                if ((uint64_t)me.vhead + indices[me.ihead + i] >= n_vertices)
+                    return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_meshes: mesh " + std::to_string(m) + " references a vertex past vertices[]");
+            total_tris += me.tri_count;
+        }
+        if (total_tris >= 0x7FFFFFFFull) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_upload_meshes: too many triangles");
+        for (uint32_t v = 0; v < n_vertices; ++v)
+            if (!finite3(vertices[v].position) || !finite3(vertices[v].normal) || !std::isfinite(vertices[v].uv[0]) || !std::isfinite(vertices[v].uv[1]))
+                return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_meshes: vertex " + std::to_string(v) + " is not finite");
+
+        hipStream_t s = ctx->stream;
+        PT_HIP(ctx, hipStreamSynchronize(s));
+        const uint32_t n_tris = (uint32_t)total_tris;
+        // host-side mesh table
+        std::vector<DMesh> hm(n_meshes);
+        std::vector<uint32_t> tri_mesh(n_tris), mesh_first(n_meshes);
+        uint32_t acc = 0, n_nodes = 0;
+        std::vector<uint32_t> node_base(n_meshes, PT_NONE);
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            const PtMesh& me = meshes[m];
+            DMesh& d = hm[m];
+            float ma = 0.0f;
+            for (int k = 0; k < 3; ++k) {
+                d.bmin[k] = me.aabb_min[k];
+                d.bmax[k] = me.aabb_max[k];
+                ma = std::max(ma, std::max(std::fabs(me.aabb_min[k]), std::fabs(me.aabb_max[k])));
+            }
+            d.tri_first = acc;
+            d.tri_count = me.tri_count;
+            d.blas_root = PT_NONE;
+            d.blas_depth = 0;
+            d.max_abs = std::isfinite(ma) ? ma : 0.0f;
+            d._pad = 0;
+            mesh_first[m] = acc;
+            for (uint32_t i = 0; i < me.tri_count; ++i) tri_mesh[acc + i] = m;
+            bool want_blas = (ctx->cfg.accel == PT_ACCEL_BVH && me.tri_count >= 2) ||
+                             (ctx->cfg.accel == PT_ACCEL_AUTO && me.tri_count > kBlasMinTris);
+            if (want_blas) {
+                node_base[m] = n_nodes;
+                n_nodes += me.tri_count - 1;
+            }
+            acc += me.tri_count;
+        }
+        PT_HIP(ctx, ctx->w_meshes.ensure(sizeof(PtMesh) * (size_t)n_meshes));
+        PT_HIP(ctx, ctx->w_indices.ensure(sizeof(uint32_t) * (size_t)n_indices));
+        PT_HIP(ctx, ctx->w_vertices.ensure(sizeof(PtVertex) * (size_t)n_vertices));
+        PT_HIP(ctx, ctx->d_meshes.ensure(sizeof(DMesh) * (size_t)n_meshes));
+        PT_HIP(ctx, ctx->d_tris.ensure(sizeof(DTri) * (size_t)n_tris));
+        PT_HIP(ctx, ctx->d_attrs.ensure(sizeof(DTriAttr) * (size_t)n_tris));
+        PT_HIP(ctx, ctx->d_tri_lo.ensure(sizeof(float4) * (size_t)n_tris));
+        PT_HIP(ctx, ctx->d_tri_hi.ensure(sizeof(float4) * (size_t)n_tris));
+        PT_HIP(ctx, ctx->t_tri_mesh.ensure(sizeof(uint32_t) * (size_t)n_tris));
+        PT_HIP(ctx, ctx->t_mesh_first.ensure(sizeof(uint32_t) * (size_t)n_meshes));
+        PT_HIP(ctx, ctx->d_blas_nodes.ensure(sizeof(BvhNode) * (size_t)n_nodes));
+        PT_HIP(ctx, ctx->t_info.ensure(sizeof(uint32_t) * (size_t)(n_meshes + 1)));
+        if (n_meshes) PT_HIP(ctx, hipMemcpyAsync(ctx->w_meshes.p, meshes, sizeof(PtMesh) * (size_t)n_meshes, hipMemcpyHostToDevice, s));
+        if (n_indices) PT_HIP(ctx, hipMemcpyAsync(ctx->w_indices.p, indices, sizeof(uint32_t) * (size_t)n_indices, hipMemcpyHostToDevice, s));
+        if (n_vertices) PT_HIP(ctx, hipMemcpyAsync(ctx->w_vertices.p, vertices, sizeof(PtVertex) * (size_t)n_vertices, hipMemcpyHostToDevice, s));
+        if (n_tris) PT_HIP(ctx, hipMemcpyAsync(ctx->t_tri_mesh.p, tri_mesh.data(), sizeof(uint32_t) * (size_t)n_tris, hipMemcpyHostToDevice, s));
+        if (n_meshes) PT_HIP(ctx, hipMemcpyAsync(ctx->t_mesh_first.p, mesh_first.data(), sizeof(uint32_t) * (size_t)n_meshes, hipMemcpyHostToDevice, s));
+        if (n_tris) {
+            k_build_tris<<<div_up(n_tris, 256), 256, 0, s>>>(ctx->w_meshes.as<WMesh>(), ctx->t_tri_mesh.as<uint32_t>(),
+                                                             ctx->t_mesh_first.as<uint32_t>(), ctx->w_indices.as<uint32_t>(),
+                                                             ctx->w_vertices.as<WVertex>(), n_tris, ctx->d_tris.as<DTri>(),
+                                                             ctx->d_attrs.as<DTriAttr>(), ctx->d_tri_lo.as<float4>(),
+                                                             ctx->d_tri_hi.as<float4>());
+            PT_HIP(ctx, hipGetLastError());
+        }
+        PT_HIP(ctx, hipMemsetAsync(ctx->t_info.p, 0, sizeof(uint32_t) * (size_t)(n_meshes + 1), s));
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            if (node_base[m] == PT_NONE) continue;
+            int rc = build_lbvh(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), hm[m].tri_first, hm[m].tri_count,
+                                ctx->d_blas_nodes.as<BvhNode>() + node_base[m], node_base[m], ctx->t_info.as<uint32_t>() + m);
+            if (rc != PT_OK) return rc;
+            hm[m].blas_root = node_base[m];
+        }
+        std::vector<uint32_t> depths(n_meshes + 1, 0);
+        PT_HIP(ctx, hipMemcpyAsync(depths.data(), ctx->t_info.p, sizeof(uint32_t) * (size_t)(n_meshes + 1), hipMemcpyDeviceToHost, s));
+        PT_HIP(ctx, hipStreamSynchronize(s));
+        uint32_t max_depth = 0;
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            hm[m].blas_depth = depths[m];
+            if (node_base[m] != PT_NONE) max_depth = std::max(max_depth, depths[m]);
+        }
+        if (n_meshes) PT_HIP(ctx, hipMemcpyAsync(ctx->d_meshes.p, hm.data(), sizeof(DMesh) * (size_t)n_meshes, hipMemcpyHostToDevice, s));
+        PT_HIP(ctx, hipStreamSynchronize(s));
+        ctx->h_meshes.swap(hm);
+        ctx->h_blas_nodes_base.swap(node_base);
+        ctx->n_meshes = n_meshes;
+        ctx->n_tris = n_tris;
+        ctx->n_blas_nodes = n_nodes;
+        ctx->max_blas_depth = max_depth;
+        ctx->have_meshes = true;
+        ctx->acc_frames = 0;
+        // instance data depends on the mesh table (world boxes, flat triangle ids)
+        if (ctx->have_objects) return rebuild_objects(ctx);
+        return PT_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, PT_ERR_OUT_OF_MEMORY, "pt_upload_meshes: host allocation failed");
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_upload_meshes: unexpected exception");
+    }
+}
+
+// ---- materials --------------------------------------------------------------------------------
+int pt_upload_materials(pt_ctx* ctx, const PtMaterial* materials, uint32_t n_materials, const PtTexture* textures,
+                        uint32_t n_textures, const float* texture_data, uint32_t n_texture_data) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if ((n_materials && !materials) || (n_textures && !textures) || (n_texture_data && !texture_data))
+            return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_materials: null array with non-zero count");
+        for (uint32_t m = 0; m < n_materials; ++m) {
+            const uint32_t t[4] = {materials[m].albedo_texture, materials[m].emissive_texture,
+                                   materials[m].metallic_roughness_texture, materials[m].normal_map_texture};
+            for (uint32_t k : t)
+                if (k != PT_U32_MAX && k >= n_textures)
+                    return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_materials: material " + std::to_string(m) + " references a texture past textures[]");
+        }
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        PT_HIP(ctx, hipStreamSynchronize(s));
+        PT_HIP(ctx, ctx->d_materials.ensure(sizeof(PtMaterial) * (size_t)n_materials));
+        PT_HIP(ctx, ctx->d_textures.ensure(sizeof(PtTexture) * (size_t)n_textures));
+        PT_HIP(ctx, ctx->d_texdata.ensure(sizeof(float) * (size_t)n_texture_data));
+        if (n_materials) PT_HIP(ctx, hipMemcpyAsync(ctx->d_materials.p, materials, sizeof(PtMaterial) * (size_t)n_materials, hipMemcpyHostToDevice, s));
+        if (n_textures) PT_HIP(ctx, hipMemcpyAsync(ctx->d_textures.p, textures, sizeof(PtTexture) * (size_t)n_textures, hipMemcpyHostToDevice, s));
+        if (n_texture_data) PT_HIP(ctx, hipMemcpyAsync(ctx->d_texdata.p, texture_data, sizeof(float) * (size_t)n_texture_data, hipMemcpyHostToDevice, s));
+        PT_HIP(ctx, hipStreamSynchronize(s));
+        ctx->n_materials = n_materials;
+        ctx->n_textures = n_textures;
+        ctx->n_texdata = n_texture_data;
+        ctx->have_materials = true;
+        ctx->acc_frames = 0;
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_upload_materials: unexpected exception");
+    }
+}
+
+// ---- objects + TLAS -----------------------------------------------------------------------------
+int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (n_objects && !objects) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_objects: null array with non-zero count");
+        if (n_objects >= 0x7FFFFFFFu) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_upload_objects: too many objects");
+        for (uint32_t o = 0; o < n_objects; ++o) {
+            for (int k = 0; k < 16; ++k)
+                if (!std::isfinite(objects[o].local_to_world[k]) || !std::isfinite(objects[o].world_to_local[k]))
+                    return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_objects: object " + std::to_string(o) + " has a non-finite matrix");
+        }
+        ctx->h_objects.assign(objects, objects + n_objects);
+        ctx->have_objects = true;
+        ctx->acc_frames = 0;
+        if (!ctx->have_meshes) {  // instance data is derived once the mesh table exists
+            ctx->n_objects = n_objects;
+            return PT_OK;
+        }
+        return rebuild_objects(ctx);
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, PT_ERR_OUT_OF_MEMORY, "pt_upload_objects: host allocation failed");
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_upload_objects: unexpected exception");
+    }
+}
+
+}  // extern "C"
+
+namespace {
+
+int rebuild_objects(pt_ctx* ctx) {
+    const uint32_t n = (uint32_t)ctx->h_objects.size();
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    PT_HIP(ctx, hipStreamSynchronize(s));
+    std::vector<uint32_t> tri_base(n);
+    uint64_t acc = 0;
+    uint32_t max_mesh = 0, max_mat = 0;
+    for (uint32_t o = 0; o < n; ++o) {
+        const PtObject& ob = ctx->h_objects[o];
+        if (ob.mesh >= ctx->n_meshes) {
+            ctx->n_objects = 0;
+            ctx->have_objects = false;
+            return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_objects: object " + std::to_string(o) + " references a mesh past meshes[]");
+        }
+        tri_base[o] = (uint32_t)acc;
+        acc += ctx->h_meshes[ob.mesh].tri_count;
+        max_mesh = std::max(max_mesh, ob.mesh);
+        max_mat = std::max(max_mat, ob.mat);
+    }
+    if (acc >= 0xFFFFFFFFull) {
+        ctx->n_objects = 0;
+        ctx->have_objects = false;
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_upload_objects: more than 2^32-1 instanced triangles");
+    }
+    ctx->obj_max_mesh = max_mesh;
+    ctx->obj_max_mat = max_mat;
+    ctx->n_objects = n;
+    ctx->tlas_root = PT_NONE;
+    ctx->tlas_depth = 0;
+    ctx->use_tlas = false;
+    ctx->stats.build_ms = 0.0;
+    if (n == 0) return PT_OK;
+
+    PT_HIP(ctx, ctx->w_objects.ensure(sizeof(PtObject) * (size_t)n));
+    PT_HIP(ctx, ctx->d_objects.ensure(sizeof(DObject) * (size_t)n));
+    PT_HIP(ctx, ctx->d_obj_lo.ensure(sizeof(float4) * (size_t)n));
+    PT_HIP(ctx, ctx->d_obj_hi.ensure(sizeof(float4) * (size_t)n));
+    PT_HIP(ctx, ctx->d_tri_base.ensure(sizeof(uint32_t) * (size_t)n));
+    PT_HIP(ctx, ctx->t_info.ensure(sizeof(uint32_t) * (size_t)(ctx->n_meshes + 1)));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->w_objects.p, ctx->h_objects.data(), sizeof(PtObject) * (size_t)n, hipMemcpyHostToDevice, s));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_tri_base.p, tri_base.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    PT_HIP(ctx, hipEventRecord(ctx->evb0, s));
+    k_prep_objects<<<div_up(n, 256), 256, 0, s>>>(ctx->w_objects.as<WObject>(), ctx->d_tri_base.as<uint32_t>(),
+                                                  ctx->d_meshes.as<DMesh>(), n, ctx->d_objects.as<DObject>(),
+                                                  ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>());
+    PT_HIP(ctx, hipGetLastError());
+    const bool want_tlas = (ctx->cfg.accel == PT_ACCEL_BVH) || (ctx->cfg.accel == PT_ACCEL_AUTO && n > kTlasMinObjects);
+    uint32_t depth = 0;
+    if (want_tlas) {
+        if (n == 1) {
+            ctx->tlas_root = PT_LEAF_BIT | 0u;
+        } else {
+            PT_HIP(ctx, ctx->d_tlas_nodes.ensure(sizeof(BvhNode) * (size_t)(n - 1)));
+            uint32_t* slot = ctx->t_info.as<uint32_t>() + ctx->n_meshes;
+            PT_HIP(ctx, hipMemsetAsync(slot, 0, sizeof(uint32_t), s));
+            int rc = build_lbvh(ctx, ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_nodes.as<BvhNode>(), 0, slot);
+            if (rc != PT_OK) return rc;
+            PT_HIP(ctx, hipMemcpyAsync(&depth, slot, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            ctx->tlas_root = 0;
+        }
+        ctx->use_tlas = true;
+    }
+    PT_HIP(ctx, hipEventRecord(ctx->evb1, s));
+    PT_HIP(ctx, hipStreamSynchronize(s));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->evb0, ctx->evb1) == hipSuccess) ctx->stats.build_ms = ms;
+    ctx->tlas_depth = depth;
+    return PT_OK;
+}
+
+uint32_t stack_depth_needed(const pt_ctx* ctx) {
+    uint32_t d = ctx->max_blas_depth + 1;
+    if (ctx->use_tlas) d += ctx->tlas_depth + 1;
+    return std::max<uint32_t>(d, 2);
+}
+
+int check_ready(pt_ctx* ctx, const char* who) {
+    if (!ctx->have_meshes || !ctx->have_materials || !ctx->have_objects)
+        return fail(ctx, PT_ERR_NOT_READY, std::string(who) + ": meshes, materials and objects must all have been uploaded");
+    if (ctx->n_objects) {
+        if (ctx->obj_max_mesh >= ctx->n_meshes) return fail(ctx, PT_ERR_INVALID_SCENE, std::string(who) + ": an object references a mesh past meshes[]");
+        if (ctx->obj_max_mat >= ctx->n_materials) return fail(ctx, PT_ERR_INVALID_SCENE, std::string(who) + ": an object references a material past materials[]");
+    }
+    if (stack_depth_needed(ctx) > kMaxStackDepth)
+        return fail(ctx, PT_ERR_UNSUPPORTED, std::string(who) + ": acceleration structure deeper than the traversal stack; create the context with PT_ACCEL_BRUTE");
+    return PT_OK;
+}
+
+SceneView make_view(const pt_ctx* ctx) {
+    SceneView v;
+    v.objects = ctx->d_objects.as<DObject>();
+    v.meshes = ctx->d_meshes.as<DMesh>();
+    v.tris = ctx->d_tris.as<DTri>();
+    v.tri_attrs = ctx->d_attrs.as<DTriAttr>();
+    v.blas_nodes = ctx->d_blas_nodes.as<BvhNode>();
+    v.tlas_nodes = ctx->d_tlas_nodes.as<BvhNode>();
+    v.materials = ctx->d_materials.as<DMaterial>();
+    v.textures = ctx->d_textures.as<DTexture>();
+    v.texture_data = ctx->d_texdata.as<float>();
+    v.n_objects = ctx->n_objects;
+    v.n_texture_data = ctx->n_texdata;
+    v.tlas_root = ctx->tlas_root;
+    v.tie_lowest = (ctx->cfg.tie_rule == PT_TIE_LOWEST) ? 1u : 0u;
+    return v;
+}
+
+int finish_timing(pt_ctx* ctx) {
+    if (!ctx->timing_pending) return PT_OK;
+    PT_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.0f;
+    PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    DCounters c;
+    PT_HIP(ctx, hipMemcpy(&c, ctx->d_counters.p, sizeof c, hipMemcpyDeviceToHost));
+    ctx->stats.trace_ms = ms;
+    ctx->stats.trace_launches = 1;
+    ctx->stats.rays = c.rays;
+    ctx->stats.xforms = c.xforms;
+    ctx->stats.box_tests = c.box_tests;
+    ctx->stats.tri_tests = c.tri_tests;
+    ctx->stats.shades = c.shades;
+    ctx->stats.paths = ctx->last_paths;
+    ctx->stats.rays_reference = c.rays + ctx->last_primary;
+    ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u);
+    ctx->timing_pending = false;
+    return PT_OK;
+}
+
+// Enqueue one frame on `s`, image to device memory `out`.
+int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
+    int rc = check_ready(ctx, "pt_render");
+    if (rc != PT_OK) return rc;
+    if (f->width == 0 || f->height == 0) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: zero-sized frame");
+    if ((uint64_t)f->width * f->height > (1ull << 28)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: frame larger than 2^28 pixels");
+    const uint32_t pc = f->part_count ? f->part_count : 1u;
+    if (f->part_index >= pc) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: part_index >= part_count");
+    rc = finish_timing(ctx);
+    if (rc != PT_OK) return rc;
+
+    const size_t n_pix = (size_t)f->width * f->height;
+    PT_HIP(ctx, ctx->d_aux_obj.ensure(4 * n_pix));
+    PT_HIP(ctx, ctx->d_aux_flat.ensure(4 * n_pix));
+    PT_HIP(ctx, ctx->d_aux_t.ensure(4 * n_pix));
+    PT_HIP(ctx, ctx->d_aux_rays.ensure(4 * n_pix));
+    ctx->aux_w = f->width;
+    ctx->aux_h = f->height;
+
+    FrameParams fp;
+    std::memcpy(fp.wfv, f->world_from_view, sizeof fp.wfv);
+    std::memcpy(fp.vfc, f->view_from_clip, sizeof fp.vfc);
+    fp.width = f->width;
+    fp.height = f->height;
+    fp.time = f->time;
+    fp.bounces = f->settings.bounces;
+    fp.samples = f->settings.samples;
+    fp.sky[0] = f->settings.sky_color[0];
+    fp.sky[1] = f->settings.sky_color[1];
+    fp.sky[2] = f->settings.sky_color[2];
+    fp.part_index = f->part_index;
+    fp.part_count = pc;
+    fp.tiles_x = div_up(f->width, 8);
+    fp.tiles_y = div_up(f->height, 8);
+    const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
+    fp.n_local_tiles = (f->part_index < n_tiles) ? (n_tiles - f->part_index + pc - 1) / pc : 0u;
+
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
+    if (pc > 1) {
+        PT_HIP(ctx, hipMemsetAsync(out, 0, 16 * n_pix, s));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_obj.p, 0xFF, 4 * n_pix, s));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_flat.p, 0xFF, 4 * n_pix, s));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_t.p, 0, 4 * n_pix, s));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_rays.p, 0, 4 * n_pix, s));
+    }
+    SceneView sv = make_view(ctx);
+    const uint32_t depth = stack_depth_needed(ctx);
+    const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t);
+    const uint32_t grid = div_up(fp.n_local_tiles, 4);
+    PT_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    if (grid) {
+        float4* o4 = reinterpret_cast<float4*>(out);
+        uint32_t* ao = ctx->d_aux_obj.as<uint32_t>();
+        uint32_t* af = ctx->d_aux_flat.as<uint32_t>();
+        float* at = ctx->d_aux_t.as<float>();
+        uint32_t* ar = ctx->d_aux_rays.as<uint32_t>();
+        DCounters* dc = ctx->d_counters.as<DCounters>();
+        const bool st = ctx->stats_detail;
+        if (ctx->use_tlas) {
+            if (st) k_render<true, true><<<grid, 256, lds, s>>>(sv, fp, depth, o4, ao, af, at, ar, dc);
+            else k_render<true, false><<<grid, 256, lds, s>>>(sv, fp, depth, o4, ao, af, at, ar, dc);
+        } else {
+            if (st) k_render<false, true><<<grid, 256, lds, s>>>(sv, fp, depth, o4, ao, af, at, ar, dc);
+            else k_render<false, false><<<grid, 256, lds, s>>>(sv, fp, depth, o4, ao, af, at, ar, dc);
+        }
+        PT_HIP(ctx, hipGetLastError());
+    }
+    PT_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    ctx->timing_pending = true;
+    // pixels of this partition
+    uint64_t local_pixels = 0;
+    if (pc == 1) {
+        local_pixels = n_pix;
+    } else {
+        for (uint32_t k = f->part_index; k < n_tiles; k += pc) {
+            uint32_t ty = k / fp.tiles_x, tx = k - ty * fp.tiles_x;
+            uint32_t w = std::min(8u, f->width - tx * 8), h = std::min(8u, f->height - ty * 8);
+            local_pixels += (uint64_t)w * h;
+        }
+    }
+    ctx->last_paths = local_pixels * fp.samples;
+    ctx->last_primary = (fp.bounces > 0 && fp.samples > 0) ? local_pixels * (uint64_t)(fp.samples - 1) : 0;
+
+    if (f->flags & (PT_FRAME_ACCUMULATE | PT_FRAME_RESET)) {
+        if ((f->flags & PT_FRAME_RESET) || ctx->acc_w != f->width || ctx->acc_h != f->height) {
+            PT_HIP(ctx, ctx->d_acc.ensure(16 * n_pix));
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_acc.p, 0, 16 * n_pix, s));
+            ctx->acc_w = f->width;
+            ctx->acc_h = f->height;
+            ctx->acc_frames = 0;
+        }
+        if (f->flags & PT_FRAME_ACCUMULATE) {
+            ctx->acc_frames += 1;
+            k_accumulate<<<div_up((uint32_t)n_pix, 256), 256, 0, s>>>(ctx->d_acc.as<float4>(), reinterpret_cast<float4*>(out),
+                                                                      (uint32_t)n_pix, (float)ctx->acc_frames);
+            PT_HIP(ctx, hipGetLastError());
+        }
+    }
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_render_device(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_device, void* hip_stream) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!frame || !out_rgba_device) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_device: null argument");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
+        int rc = render_enqueue(ctx, frame, out_rgba_device, s);
+        if (rc != PT_OK) return rc;
+        if (!hip_stream) PT_HIP(ctx, hipStreamSynchronize(s));
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_render_device: unexpected exception");
+    }
+}
+
+int pt_render(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_host) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!frame || !out_rgba_host) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: null argument");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        const size_t bytes = (size_t)16 * frame->width * frame->height;
+        PT_HIP(ctx, ctx->d_out.ensure(bytes));
+        int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), ctx->stream);
+        if (rc != PT_OK) return rc;
+        PT_HIP(ctx, hipMemcpyAsync(out_rgba_host, ctx->d_out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_render: unexpected exception");
+    }
+}
+
+int pt_query(pt_ctx* ctx, const PtRay* rays_host, uint32_t n_rays, PtHit* hits_host) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (n_rays && (!rays_host || !hits_host)) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_query: null argument");
+        int rc = check_ready(ctx, "pt_query");
+        if (rc != PT_OK) return rc;
+        if (n_rays == 0) return PT_OK;
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        PT_HIP(ctx, ctx->d_rays.ensure(sizeof(PtRay) * (size_t)n_rays));
+        PT_HIP(ctx, ctx->d_hits.ensure(sizeof(PtHit) * (size_t)n_rays));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_rays.p, rays_host, sizeof(PtRay) * (size_t)n_rays, hipMemcpyHostToDevice, s));
+        SceneView sv = make_view(ctx);
+        const uint32_t depth = stack_depth_needed(ctx);
+        const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t);
+        if (ctx->use_tlas) k_query<true><<<div_up(n_rays, 256), 256, lds, s>>>(sv, depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        else k_query<false><<<div_up(n_rays, 256), 256, lds, s>>>(sv, depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        PT_HIP(ctx, hipGetLastError());
+        PT_HIP(ctx, hipMemcpyAsync(hits_host, ctx->d_hits.p, sizeof(PtHit) * (size_t)n_rays, hipMemcpyDeviceToHost, s));
+        PT_HIP(ctx, hipStreamSynchronize(s));
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_query: unexpected exception");
+    }
+}
+
+int pt_read_aux(pt_ctx* ctx, uint32_t kind, void* out_host, size_t out_bytes) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!out_host) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_read_aux: null argument");
+        if (ctx->aux_w == 0) return fail(ctx, PT_ERR_NOT_READY, "pt_read_aux: no frame has been rendered");
+        const size_t need = (size_t)4 * ctx->aux_w * ctx->aux_h;
+        if (out_bytes < need) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_read_aux: buffer too small");
+        const DevBuf* src = nullptr;
+        switch (kind) {
+            case PT_AUX_PRIMARY_OBJECT: src = &ctx->d_aux_obj; break;
+            case PT_AUX_PRIMARY_FLAT_ID: src = &ctx->d_aux_flat; break;
+            case PT_AUX_PRIMARY_T: src = &ctx->d_aux_t; break;
+            case PT_AUX_RAY_COUNT: src = &ctx->d_aux_rays; break;
+            default: return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_read_aux: unknown kind");
+        }
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        int rc = finish_timing(ctx);
+        if (rc != PT_OK) return rc;
+        PT_HIP(ctx, hipMemcpy(out_host, src->p, need, hipMemcpyDeviceToHost));
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_read_aux: unexpected exception");
+    }
+}
+
+int pt_set_stats_detail(pt_ctx* ctx, int detail) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    ctx->stats_detail = detail != 0;
+    return PT_OK;
+}
+
+int pt_get_stats(pt_ctx* ctx, PtStats* out) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!out) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_get_stats: null argument");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        int rc = finish_timing(ctx);
+        if (rc != PT_OK) return rc;
+        *out = ctx->stats;
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_get_stats: unexpected exception");
+    }
+}
+
+int pt_debug_check_accel(pt_ctx* ctx, uint32_t* n_errors, uint32_t* tlas_depth, uint32_t* max_blas_depth) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!n_errors) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_debug_check_accel: null argument");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        PT_HIP(ctx, ctx->t_errors.ensure(sizeof(uint32_t)));
+        PT_HIP(ctx, hipMemsetAsync(ctx->t_errors.p, 0, sizeof(uint32_t), s));
+        for (uint32_t m = 0; m < ctx->n_meshes; ++m) {
+            if (ctx->h_blas_nodes_base[m] == PT_NONE) continue;
+            const uint32_t ni = ctx->h_meshes[m].tri_count - 1;
+            k_check_bvh<<<div_up(ni, 256), 256, 0, s>>>(ctx->d_blas_nodes.as<BvhNode>() + ctx->h_blas_nodes_base[m],
+                                                        ctx->h_blas_nodes_base[m], ni, ctx->d_tri_lo.as<float4>(),
+                                                        ctx->d_tri_hi.as<float4>(), ctx->h_meshes[m].tri_first,
+                                                        ctx->t_errors.as<uint32_t>());
+        }
+        if (ctx->use_tlas && ctx->n_objects > 1)
+            k_check_bvh<<<div_up(ctx->n_objects - 1, 256), 256, 0, s>>>(ctx->d_tlas_nodes.as<BvhNode>(), 0, ctx->n_objects - 1,
+                                                                        ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0,
+                                                                        ctx->t_errors.as<uint32_t>());
+        PT_HIP(ctx, hipGetLastError());
+        PT_HIP(ctx, hipMemcpyAsync(n_errors, ctx->t_errors.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        PT_HIP(ctx, hipStreamSynchronize(s));
+        if (tlas_depth) *tlas_depth = ctx->use_tlas ? ctx->tlas_depth : 0;
+        if (max_blas_depth) *max_blas_depth = ctx->max_blas_depth;
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_debug_check_accel: unexpected exception");
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// pt_scene.h — device-side scene layout (HBM resident, rebuilt from the wire
+// structs of include/pt_amd.h at upload time).
+#pragma once
+
+#include "pt_math.h"
+
+// One instance. 128 B, read as 8 x dwordx4 (scalar loads when the object index is wave-uniform).
+struct DObject {
+    Affine w2l;          // world_to_local rows (reference src/query.wgsl:73-74)
+    Affine l2w;          // local_to_world rows (reference src/query.wgsl:118-119)
+    uint32_t mat;
+    uint32_t mesh;
+    uint32_t tri_base;   // flat triangle id of this object's triangle 0 (order of the reference's double loop)
+    uint32_t _pad0;
+    uint32_t _pad1[4];
+};
+static_assert(sizeof(DObject) == 128, "DObject");
+
+// One mesh. 48 B.
+struct DMesh {
+    float bmin[3];
+    uint32_t tri_first;   // first record of this mesh in tris[] / tri_attrs[]
+    float bmax[3];
+    uint32_t tri_count;
+    uint32_t blas_root;   // node index into blas_nodes[], a leaf reference (PT_LEAF_BIT|tri), or PT_NONE (= loop over all triangles)
+    uint32_t blas_depth;  // longest root-to-leaf path, in nodes
+    float max_abs;        // largest |coordinate| of the mesh AABB
+    uint32_t _pad;
+};
+static_assert(sizeof(DMesh) == 48, "DMesh");
+
+// Geometry of one triangle, precomputed with the arithmetic of reference src/query.wgsl:95-97:
+//   a = va.position, e_ab = vb.position - va.position, e_ac = vc.position - va.position, n = cross(e_ab, e_ac)
+// 48 B = 3 x dwordx4.
+struct DTri {
+    float4 q0;  // a.x a.y a.z e_ab.x
+    float4 q1;  // e_ab.y e_ab.z e_ac.x e_ac.y
+    float4 q2;  // e_ac.z n.x n.y n.z
+};
+static_assert(sizeof(DTri) == 48, "DTri");
+
+// Shading attributes of one triangle, fetched once per ray for the winning triangle. 64 B.
+struct DTriAttr {
+    float4 q0;  // na.x na.y na.z nb.x
+    float4 q1;  // nb.y nb.z nc.x nc.y
+    float4 q2;  // nc.z uva.x uva.y uvb.x
+    float4 q3;  // uvb.y uvc.x uvc.y 0
+};
+static_assert(sizeof(DTriAttr) == 64, "DTriAttr");
+
+// Binary BVH node holding the boxes of both children. 64 B = 4 x dwordx4.
+// A child reference with PT_LEAF_BIT set is a primitive (triangle of the mesh for a BLAS, object for the TLAS).
+#define PT_LEAF_BIT 0x80000000u
+struct BvhNode {
+    float4 lo_l;  // left  min.xyz, w = bits of the left child reference
+    float4 hi_l;  // left  max.xyz, w = bits of the left subtree's depth (build bookkeeping)
+    float4 lo_r;  // right min.xyz, w = bits of the right child reference
+    float4 hi_r;  // right max.xyz, w = bits of the right subtree's depth
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode");
+
+struct DMaterial {  // == PtMaterial (reference src/raytrace.wgsl:29-39)
+    float albedo[3];
+    uint32_t albedo_texture;
+    float emissive[3];
+    uint32_t emissive_texture;
+    float roughness;
+    float metallic;
+    uint32_t metallic_roughness_texture;
+    float reflectance;
+    uint32_t normal_map_texture;
+    uint32_t _pad[3];
+};
+static_assert(sizeof(DMaterial) == 64, "DMaterial");
+
+struct DTexture {  // == PtTexture (reference src/raytrace.wgsl:41-46)
+    uint32_t width, height, offset, format;
+};
+
+// Everything a trace kernel reads, passed by value as one kernel argument.
+struct SceneView {
+    const DObject* __restrict__ objects;
+    const DMesh* __restrict__ meshes;
+    const DTri* __restrict__ tris;
+    const DTriAttr* __restrict__ tri_attrs;
+    const BvhNode* __restrict__ blas_nodes;
+    const BvhNode* __restrict__ tlas_nodes;
+    const DMaterial* __restrict__ materials;
+    const DTexture* __restrict__ textures;
+    const float* __restrict__ texture_data;
+    uint32_t n_objects;
+    uint32_t n_texture_data;
+    uint32_t tlas_root;   // node index, leaf reference, or PT_NONE when there are no objects
+    uint32_t tie_lowest;  // 0: equal distances go to the later (object, triangle) as in the reference; 1: to the earlier
+};
+
+// Per-frame constants.
+struct FrameParams {
+    float wfv[16];   // view.world_from_view, column-major
+    float vfc[16];   // view.view_from_clip, column-major
+    uint32_t width, height;
+    float time;
+    uint32_t bounces, samples;
+    float sky[3];
+    uint32_t part_index, part_count;
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_local_tiles;
+};
+
+// Work counters accumulated by the trace kernels (one atomic per wave and counter).
+struct DCounters {
+    unsigned long long rays;
+    unsigned long long xforms;
+    unsigned long long box_tests;
+    unsigned long long tri_tests;
+    unsigned long long shades;
+    unsigned long long _pad[3];
+};

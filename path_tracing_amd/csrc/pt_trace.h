@@ -1,0 +1,556 @@
+// pt_trace.h — the two device stages of the hot path:
+//   closest_hit_*  replaces hit_all / hit_mesh / hit_box   (reference src/query.wgsl:55-147)
+//   k_render       replaces fragment() and its helpers      (reference src/raytrace.wgsl:60-277)
+//
+// Closest hit keeps the reference's per-candidate arithmetic exactly (ray moved to the
+// object's local space with world_to_local, the quirky mesh-AABB gate, Moeller-Trumbore
+// with the un-normalised back-face threshold) and only changes WHICH candidates are
+// visited: objects through a TLAS and triangles through a per-mesh BLAS whose slab tests
+// are padded so that they can only cull what the exact test would reject. The winner is
+// chosen by an order-independent rule, (smaller t) or (equal t and later/earlier
+// (object, triangle)), which reproduces the reference's sequential `t > hit_record.t`
+// reject test for any visiting order.
+#pragma once
+
+#include "pt_scene.h"
+
+struct Best {
+    float t;
+    uint32_t obj;
+    uint32_t tri;
+    float u, v;
+};
+
+struct HitInfo {
+    uint32_t obj;
+    v3 p, n;
+    float u, v;  // hit_record.uv
+};
+
+struct LaneCounters {
+    uint32_t rays, xforms, box_tests, tri_tests, shades;
+};
+
+// Per-lane traversal stack in LDS: entry [level][lane], so a wave's push/pop touches 64 consecutive banks.
+struct LdsStack {
+    uint32_t* base;  // &s_stack[wave][0][lane]
+    PT_DEV void put(int level, uint32_t v) { base[level * 64] = v; }
+    PT_DEV uint32_t get(int level) const { return base[level * 64]; }
+};
+
+PT_DEV bool candidate_wins(float t, uint32_t obj, uint32_t tri, const Best& b, uint32_t tie_lowest) {
+    if (t < b.t) return true;
+    if (t == b.t) {
+        if (b.obj == PT_NONE) return true;
+        if (!tie_lowest) return (obj > b.obj) || (obj == b.obj && tri > b.tri);
+        return (obj < b.obj) || (obj == b.obj && tri < b.tri);
+    }
+    return false;
+}
+
+// reference src/query.wgsl:95-121, with edges and normal precomputed at upload by the same operations.
+template <bool STATS>
+PT_DEV void tri_test(const float4 q0, const float4 q1, const float4 q2, v3 o, v3 d, uint32_t obj, uint32_t tri,
+                     uint32_t tie_lowest, Best& best, LaneCounters& cnt) {
+    if (STATS) cnt.tri_tests++;
+    v3 a = V3(q0.x, q0.y, q0.z);
+    v3 e_ab = V3(q0.w, q1.x, q1.y);
+    v3 e_ac = V3(q1.z, q1.w, q2.x);
+    v3 n = V3(q2.y, q2.z, q2.w);
+    v3 ao = sub3(o, a);
+    v3 dao = cross3(ao, d);
+    float det = -dot3(d, n);
+    if (det < PT_EPSILON) return;
+    float inv_det = pt_div(1.0f, det);
+    float t = dot3(ao, n) * inv_det;
+    float u = dot3(e_ac, dao) * inv_det;
+    float v = (-dot3(e_ab, dao)) * inv_det;
+    float w = 1.0f - u - v;
+    if (t < PT_T_MIN || u < 0.0f || v < 0.0f || w < 0.0f) return;
+    if (candidate_wins(t, obj, tri, best, tie_lowest)) {
+        best.t = t;
+        best.obj = obj;
+        best.tri = tri;
+        best.u = u;
+        best.v = v;
+    }
+}
+
+// reference src/query.wgsl:127-147; also returns 1/dir for reuse by the BLAS walk.
+PT_DEV float hit_box_exact(const float* bmin, const float* bmax, v3 pos, v3 dir, v3& inv) {
+    inv = V3(pt_div(1.0f, dir.x), pt_div(1.0f, dir.y), pt_div(1.0f, dir.z));
+    float tminx = (bmin[0] - pos.x) * inv.x, tminy = (bmin[1] - pos.y) * inv.y, tminz = (bmin[2] - pos.z) * inv.z;
+    float tmaxx = (bmax[0] - pos.x) * inv.x, tmaxy = (bmax[1] - pos.y) * inv.y, tmaxz = (bmax[2] - pos.z) * inv.z;
+    float t1x = pt_min(tminx, tmaxx), t1y = pt_min(tminy, tmaxy), t1z = pt_min(tminz, tmaxz);
+    float t2x = pt_max(tminx, tmaxx), t2y = pt_max(tminy, tmaxy), t2z = pt_max(tminz, tmaxz);
+    float dst_near = pt_max(pt_max(t1x, t1y), t1z);
+    float dst_far = pt_min(pt_min(t2x, t2y), t2z);
+    bool hit = (dst_far >= dst_near) && (dst_far > 0.0f);
+    if (hit) return (dst_near > 0.0f) ? dst_near : PT_WGSL_INFINITY;
+    return 0.0f;
+}
+
+// Conservative ray/box test used only for culling. The box is grown by `pad` on every side
+// (folded into ka/kb), reciprocals are clamped to +-2^100 so that axis-parallel rays stay finite,
+// NaNs drop out of min/max (= "no constraint"), and the interval is clipped to [0, tmax].
+struct SlabRay {
+    v3 inv;     // clamped 1/dir
+    v3 ka, kb;  // -(o+pad)*inv, -(o-pad)*inv
+};
+PT_DEV SlabRay make_slab_ray(v3 o, v3 inv_exact, float pad) {
+    SlabRay s;
+    const float big = 0x1p100f;
+    s.inv = V3(pt_min(pt_max(inv_exact.x, -big), big), pt_min(pt_max(inv_exact.y, -big), big),
+               pt_min(pt_max(inv_exact.z, -big), big));
+    s.ka = V3(-(o.x + pad) * s.inv.x, -(o.y + pad) * s.inv.y, -(o.z + pad) * s.inv.z);
+    s.kb = V3(-(o.x - pad) * s.inv.x, -(o.y - pad) * s.inv.y, -(o.z - pad) * s.inv.z);
+    return s;
+}
+PT_DEV bool slab_test(const SlabRay& s, float4 lo, float4 hi, float tmax, float& tnear) {
+    float ax = pt_fma(lo.x, s.inv.x, s.ka.x), bx = pt_fma(hi.x, s.inv.x, s.kb.x);
+    float ay = pt_fma(lo.y, s.inv.y, s.ka.y), by = pt_fma(hi.y, s.inv.y, s.kb.y);
+    float az = pt_fma(lo.z, s.inv.z, s.ka.z), bz = pt_fma(hi.z, s.inv.z, s.kb.z);
+    float tn = pt_max(pt_max(pt_min(ax, bx), pt_min(ay, by)), pt_max(pt_min(az, bz), 0.0f));
+    float tf = pt_min(pt_min(pt_max(ax, bx), pt_max(ay, by)), pt_min(pt_max(az, bz), tmax));
+    tnear = tn;
+    return tn <= tf;
+}
+
+// Walk one mesh's BLAS in the object's local space. `sp0` is the first free stack level.
+template <bool STATS>
+PT_DEV void blas_walk(const SceneView& sc, uint32_t root, uint32_t tri_first, float mesh_max_abs, uint32_t obj, v3 lo,
+                      v3 ld, v3 inv_exact, Best& best, LdsStack stk, int sp0, LaneCounters& cnt) {
+    float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) +
+                            mesh_max_abs);
+    SlabRay sr = make_slab_ray(lo, inv_exact, pad);
+    int sp = sp0;
+    uint32_t node = root;
+    while (true) {
+        if (!(node & PT_LEAF_BIT)) {
+            const BvhNode* N = &sc.blas_nodes[node];
+            float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
+            if (STATS) cnt.box_tests += 2;
+            float tl, tr;
+            bool hit_l = slab_test(sr, ll, hl, best.t, tl);
+            bool hit_r = slab_test(sr, lr, hr, best.t, tr);
+            uint32_t cl = __float_as_uint(ll.w), cr = __float_as_uint(lr.w);
+            if (hit_l && hit_r) {
+                bool left_first = tl <= tr;
+                stk.put(sp++, left_first ? cr : cl);
+                node = left_first ? cl : cr;
+                continue;
+            }
+            if (hit_l) { node = cl; continue; }
+            if (hit_r) { node = cr; continue; }
+        } else {
+            uint32_t tri = node & ~PT_LEAF_BIT;
+            const DTri* T = &sc.tris[tri_first + tri];
+            tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, best, cnt);
+        }
+        if (sp == sp0) break;
+        node = stk.get(--sp);
+    }
+}
+
+// hit_mesh for one object (reference src/query.wgsl:66-125): transform, exact gate, triangles.
+// UNIFORM = the object (and therefore the mesh) is the same in every lane of the wave.
+template <bool STATS>
+PT_DEV void object_test(const SceneView& sc, const DObject* ob, uint32_t obj, v3 ro, v3 rd, Best& best, LdsStack stk,
+                        int sp0, LaneCounters& cnt) {
+    Affine w2l = ob->w2l;
+    uint32_t mesh_id = ob->mesh;
+    v3 lo = xform_point(w2l, ro);
+    v3 ld = xform_dir(w2l, rd);
+    const DMesh* me = &sc.meshes[mesh_id];
+    if (STATS) cnt.xforms++;
+    v3 inv;
+    float t_aabb = hit_box_exact(me->bmin, me->bmax, lo, ld, inv);
+    if (t_aabb < PT_T_MIN) return;
+    uint32_t root = me->blas_root;
+    uint32_t tri_first = me->tri_first;
+    if (root == PT_NONE) {
+        uint32_t n = me->tri_count;
+        for (uint32_t i = 0; i < n; ++i) {
+            const DTri* T = &sc.tris[tri_first + i];
+            tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, best, cnt);
+        }
+    } else {
+        blas_walk<STATS>(sc, root, tri_first, me->max_abs, obj, lo, ld, inv, best, stk, sp0, cnt);
+    }
+}
+
+// hit_all, objects visited in index order by the whole wave together (scalar loads of the
+// object, mesh and triangle records). For scenes with a handful of objects.
+template <bool STATS>
+PT_DEV void closest_hit_uniform(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk,
+                                LaneCounters& cnt) {
+    uint32_t n = sc.n_objects;
+    for (uint32_t o = 0; o < n; ++o) {
+        if (active) object_test<STATS>(sc, &sc.objects[o], o, ro, rd, best, stk, 0, cnt);
+    }
+}
+
+// hit_all through the TLAS: each lane walks the object tree on its own.
+template <bool STATS>
+PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk,
+                             LaneCounters& cnt) {
+    if (!active || sc.tlas_root == PT_NONE) return;
+    v3 inv_w = V3(pt_div(1.0f, rd.x), pt_div(1.0f, rd.y), pt_div(1.0f, rd.z));
+    float pad = 0x1p-16f * pt_max(pt_max(__builtin_fabsf(ro.x), __builtin_fabsf(ro.y)), __builtin_fabsf(ro.z));
+    SlabRay sr = make_slab_ray(ro, inv_w, pad);
+    int sp = 0;
+    uint32_t node = sc.tlas_root;
+    while (true) {
+        if (!(node & PT_LEAF_BIT)) {
+            const BvhNode* N = &sc.tlas_nodes[node];
+            float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
+            if (STATS) cnt.box_tests += 2;
+            float tl, tr;
+            bool hit_l = slab_test(sr, ll, hl, best.t, tl);
+            bool hit_r = slab_test(sr, lr, hr, best.t, tr);
+            uint32_t cl = __float_as_uint(ll.w), cr = __float_as_uint(lr.w);
+            if (hit_l && hit_r) {
+                bool left_first = tl <= tr;
+                stk.put(sp++, left_first ? cr : cl);
+                node = left_first ? cl : cr;
+                continue;
+            }
+            if (hit_l) { node = cl; continue; }
+            if (hit_r) { node = cr; continue; }
+        } else {
+            uint32_t obj = node & ~PT_LEAF_BIT;
+            object_test<STATS>(sc, &sc.objects[obj], obj, ro, rd, best, stk, sp, cnt);
+        }
+        if (sp == 0) break;
+        node = stk.get(--sp);
+    }
+}
+
+template <bool TLAS, bool STATS>
+PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
+    best.t = PT_T_MAX;
+    best.obj = PT_NONE;
+    best.tri = PT_NONE;
+    best.u = 0.0f;
+    best.v = 0.0f;
+    if (TLAS) closest_hit_tlas<STATS>(sc, ro, rd, active, best, stk, cnt);
+    else closest_hit_uniform<STATS>(sc, ro, rd, active, best, stk, cnt);
+}
+
+// The hit_record of the winner (reference src/query.wgsl:113-120), evaluated once per ray.
+PT_DEV HitInfo finalize_hit(const SceneView& sc, v3 ro, v3 rd, const Best& b) {
+    HitInfo h;
+    h.obj = b.obj;
+    h.p = V3(0, 0, 0);
+    h.n = V3(0, 0, 0);
+    h.u = 0.0f;
+    h.v = 0.0f;
+    if (b.obj == PT_NONE) return h;
+    const DObject* ob = &sc.objects[b.obj];
+    Affine w2l = ob->w2l, l2w = ob->l2w;
+    v3 lo = xform_point(w2l, ro);
+    v3 ld = xform_dir(w2l, rd);
+    uint32_t tri_first = sc.meshes[ob->mesh].tri_first;
+    const DTriAttr* A = &sc.tri_attrs[tri_first + b.tri];
+    float4 a0 = A->q0, a1 = A->q1, a2 = A->q2, a3 = A->q3;
+    float u = b.u, v = b.v;
+    float w = 1.0f - u - v;
+    v3 _p = madd3(lo, ld, b.t);
+    v3 _n = V3(pt_fma(a1.z, v, pt_fma(a0.w, u, a0.x * w)), pt_fma(a1.w, v, pt_fma(a1.x, u, a0.y * w)),
+               pt_fma(a2.x, v, pt_fma(a1.y, u, a0.z * w)));
+    h.u = pt_fma(a3.y, v, pt_fma(a2.w, u, a2.y * w));
+    h.v = pt_fma(a3.z, v, pt_fma(a3.x, u, a2.z * w));
+    h.p = xform_point(l2w, _p);
+    h.n = normalize3(xform_dir(l2w, _n));
+    return h;
+}
+
+// ---- shading: reference src/raytrace.wgsl:88-203 ----------------------------------
+
+PT_DEV float texel(const SceneView& sc, uint32_t i) { return (i < sc.n_texture_data) ? sc.texture_data[i] : 0.0f; }
+
+// src/raytrace.wgsl:120-153 (row stride is `height`, as in the reference)
+PT_DEV v3 sample_texture(const SceneView& sc, uint32_t idx, float u, float v) {
+    DTexture tx = sc.textures[idx];
+    float x = u * (float)tx.width;
+    float y = v * (float)tx.height;
+    uint32_t i = tx.offset + (pt_f2u(x) + pt_f2u(y) * tx.height) * tx.format;
+    switch (tx.format) {
+        case 1u: { float r = texel(sc, i); return V3(r, r, r); }
+        case 2u: return V3(texel(sc, i), texel(sc, i + 1u), 0.0f);
+        case 3u: return V3(texel(sc, i), texel(sc, i + 1u), texel(sc, i + 2u));
+        case 4u: {
+            float a = texel(sc, i + 3u);
+            return V3(texel(sc, i) * a, texel(sc, i + 1u) * a, texel(sc, i + 2u) * a);
+        }
+        default: return V3(1.0f, 1.0f, 1.0f);
+    }
+}
+
+// bevy_pbr::lighting::F_Schlick with f0 = 1
+PT_DEV float f_schlick_1(float f90, float u) { return pt_fma(f90 - 1.0f, pt_pow5(1.0f - u), 1.0f); }
+
+// src/raytrace.wgsl:157-203. N is hit_record.n after the normal-map multiply.
+PT_DEV void calculate_brdf(const SceneView& sc, Rng& rng, v3 ray_dir, v3 N, float hu, float hv, const DMaterial& m,
+                           v3& out_dir, v3& out_color) {
+    // hugues_moller (:102-116)
+    float ax = __builtin_fabsf(N.x), ay = __builtin_fabsf(N.y), az = __builtin_fabsf(N.z);
+    v3 tt;
+    if (ax <= ay && ax <= az) tt = V3(0.0f, -N.z, N.y);
+    else if (ay <= ax && ay <= az) tt = V3(-N.z, 0.0f, N.x);
+    else tt = V3(-N.y, N.x, 0.0f);
+    tt = normalize3(tt);
+    v3 bb = normalize3(cross3(N, tt));
+    // cosine_sample (:88-95)
+    pcg3d(rng);
+    float r0 = rand_component(rng.x), r1 = rand_component(rng.y);
+    float phi = 2.0f * PT_PI * r0;
+    float sin_theta = pt_sqrt(r1);
+    float cos_theta = pt_sqrt(1.0f - r1);
+    float sn, cs;
+    pt_sincos(phi, sn, cs);
+    v3 c = V3(sin_theta * cs, sin_theta * sn, cos_theta);
+    v3 lam = V3(pt_fma(N.x, c.z, pt_fma(bb.x, c.y, tt.x * c.x)), pt_fma(N.y, c.z, pt_fma(bb.y, c.y, tt.y * c.x)),
+                pt_fma(N.z, c.z, pt_fma(bb.z, c.y, tt.z * c.x)));
+    v3 lambertian_ray = normalize3(lam);
+    float k2 = 2.0f * dot3(N, ray_dir);
+    v3 reflection_ray = normalize3(madd3(ray_dir, N, -k2));
+    float rough_in = m.roughness;
+    float om = 1.0f - rough_in;
+    v3 L = V3(pt_fma(lambertian_ray.x, rough_in, reflection_ray.x * om),
+              pt_fma(lambertian_ray.y, rough_in, reflection_ray.y * om),
+              pt_fma(lambertian_ray.z, rough_in, reflection_ray.z * om));
+
+    v3 albedo = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    if (m.albedo_texture != PT_NONE) albedo = mul3(albedo, sample_texture(sc, m.albedo_texture, hu, hv));
+
+    v3 V = neg3(ray_dir);
+    float NdotV = pt_max(dot3(N, V), 0.0001f);
+    float cr = pt_min(pt_max(rough_in, 0.089f), 1.0f);
+    float roughness = cr * cr;
+    v3 H = normalize3(add3(L, V));
+    float NdotL = pt_saturate(dot3(N, L));
+    float LdotH = pt_saturate(dot3(L, H));
+    float f90 = pt_fma((2.0f * roughness) * LdotH, LdotH, 0.5f);
+    float fd = (f_schlick_1(f90, NdotL) * f_schlick_1(f90, NdotV)) * (1.0f / PT_PI);
+    out_dir = L;
+    out_color = scale3(scale3(albedo, fd), PT_PI);
+}
+
+PT_DEV uint32_t wave_sum_u32(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- the frame kernel ---------------------------------------------------------------
+// One lane per pixel, one wave per 8x8 pixel tile, four tiles per workgroup. The reference's
+// `for sample { for bounce {...} }` nest is flattened into one loop in which every lane always
+// has a ray of its own to trace: a lane whose path ends starts its pixel's next sample in the
+// same iteration, so lanes idle only once their pixel is completely finished. The order of RNG
+// draws and of every floating-point accumulation per pixel is the reference's.
+// The primary ray is identical for every sample of a pixel (src/raytrace.wgsl:223 restarts from
+// the same origin/direction, no jitter), so its closest hit is computed once and reused.
+template <bool TLAS, bool STATS>
+__global__ __launch_bounds__(256) void k_render(SceneView sc, FrameParams fp, uint32_t stack_depth, float4* __restrict__ out,
+                                                uint32_t* __restrict__ aux_obj, uint32_t* __restrict__ aux_flat,
+                                                float* __restrict__ aux_t, uint32_t* __restrict__ aux_rays,
+                                                DCounters* __restrict__ counters) {
+    extern __shared__ uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t local_tile = blockIdx.x * 4 + wave;
+    if (local_tile >= fp.n_local_tiles) return;  // wave-uniform
+    LdsStack stk;
+    stk.base = &s_stack[wave * stack_depth * 64 + lane];
+
+    const uint32_t tile = local_tile * fp.part_count + fp.part_index;
+    const uint32_t ty = tile / fp.tiles_x, tx = tile - ty * fp.tiles_x;
+    const uint32_t px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+    const bool valid = px < fp.width && py < fp.height;
+
+    LaneCounters cnt = {0, 0, 0, 0, 0};
+
+    // fullscreen triangle at the pixel centre; src/raytrace.wgsl:210-217
+    const float W = (float)fp.width, H = (float)fp.height;
+    const float uvx = pt_div((float)px + 0.5f, W), uvy = pt_div((float)py + 0.5f, H);
+    const float tp1 = fp.time + 1.0f;
+    const float sx = (uvx * W) * tp1, sy = (uvy * H) * tp1;
+    Rng rng;
+    rng.x = pt_f2u(sx);
+    rng.y = pt_f2u(sy);
+    rng.z = rng.x ^ rng.y;
+    const float dx = uvx * 2.0f - 1.0f;
+    const float dy = (uvy * 2.0f - 1.0f) * -1.0f;
+    const v3 origin = V3(fp.wfv[12], fp.wfv[13], fp.wfv[14]);
+    v3 temp = V3(pt_fma(fp.vfc[4], dy, fp.vfc[0] * dx) + fp.vfc[8] + fp.vfc[12],
+                 pt_fma(fp.vfc[5], dy, fp.vfc[1] * dx) + fp.vfc[9] + fp.vfc[13],
+                 pt_fma(fp.vfc[6], dy, fp.vfc[2] * dx) + fp.vfc[10] + fp.vfc[14]);
+    temp = normalize3(temp);
+    const v3 dir0 = V3(pt_fma(fp.wfv[8], temp.z, pt_fma(fp.wfv[4], temp.y, fp.wfv[0] * temp.x)),
+                       pt_fma(fp.wfv[9], temp.z, pt_fma(fp.wfv[5], temp.y, fp.wfv[1] * temp.x)),
+                       pt_fma(fp.wfv[10], temp.z, pt_fma(fp.wfv[6], temp.y, fp.wfv[2] * temp.x)));
+
+    const uint32_t bounces = fp.bounces, samples = fp.samples;
+    const v3 sky = V3(fp.sky[0], fp.sky[1], fp.sky[2]);
+    const bool any_rays = bounces > 0 && samples > 0;
+
+    // primary closest hit, once per pixel
+    Best pb;
+    pb.t = PT_T_MAX; pb.obj = PT_NONE; pb.tri = PT_NONE; pb.u = 0.0f; pb.v = 0.0f;
+    HitInfo hp;
+    hp.obj = PT_NONE; hp.p = V3(0, 0, 0); hp.n = V3(0, 0, 0); hp.u = 0.0f; hp.v = 0.0f;
+    if (any_rays) {
+        closest_hit<TLAS, STATS>(sc, origin, dir0, valid, pb, stk, cnt);
+        if (valid) {
+            cnt.rays = 1;
+            hp = finalize_hit(sc, origin, dir0, pb);
+        }
+    }
+    if (valid) {
+        const uint32_t pix = py * fp.width + px;
+        aux_obj[pix] = pb.obj;
+        aux_flat[pix] = (pb.obj != PT_NONE) ? sc.objects[pb.obj].tri_base + pb.tri : PT_NONE;
+        aux_t[pix] = pb.t;
+    }
+
+    v3 pixel_color = V3(0, 0, 0);
+    uint32_t sample = 0, bounce = 0;
+    v3 rpos = origin, rdir = dir0;
+    v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0);
+    bool active = valid && samples > 0;
+
+    while (__any(active)) {
+        // 1. closest hit for lanes that are past their first segment
+        HitInfo h = hp;
+        if (bounces > 0) {
+            bool need = active && bounce > 0;
+            if (__any(need)) {
+                Best b;
+                closest_hit<TLAS, STATS>(sc, rpos, rdir, need, b, stk, cnt);
+                if (need) {
+                    cnt.rays++;
+                    h = finalize_hit(sc, rpos, rdir, b);
+                }
+            }
+        }
+        // 2. shade (src/raytrace.wgsl:229-270) and advance the (sample, bounce) state
+        if (active) {
+            bool end_path = false;
+            if (bounces == 0) {
+                end_path = true;
+            } else if (h.obj != PT_NONE) {
+                const DMaterial m = sc.materials[sc.objects[h.obj].mat];
+                v3 emissive = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
+                if (m.emissive_texture != PT_NONE) emissive = sample_texture(sc, m.emissive_texture, h.u, h.v);
+                color = V3(pt_fma(ray_color.x, emissive.x, color.x), pt_fma(ray_color.y, emissive.y, color.y),
+                           pt_fma(ray_color.z, emissive.z, color.z));
+                v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+                if (dot3(alb, alb) < PT_EPSILON) {
+                    end_path = true;
+                } else {
+                    v3 N = h.n;
+                    if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
+                    v3 ndir, bcol;
+                    if (STATS) cnt.shades++;
+                    calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
+                    rdir = ndir;
+                    rpos = madd3(h.p, rdir, 0.001f);
+                    ray_color = mul3(ray_color, bcol);
+                    float p = pt_max(ray_color.x, pt_max(ray_color.y, ray_color.z));
+                    bounce++;
+                    if (p < PT_EPSILON || bounce >= bounces) end_path = true;
+                }
+            } else {
+                color = V3(pt_fma(ray_color.x, sky.x, color.x), pt_fma(ray_color.y, sky.y, color.y),
+                           pt_fma(ray_color.z, sky.z, color.z));
+                end_path = true;
+            }
+            if (end_path) {
+                pixel_color = add3(pixel_color, color);
+                sample++;
+                bounce = 0;
+                rpos = origin;
+                rdir = dir0;
+                ray_color = V3(1, 1, 1);
+                color = V3(0, 0, 0);
+                if (sample >= samples) active = false;
+            }
+        }
+    }
+
+    if (valid) {
+        const uint32_t pix = py * fp.width + px;
+        const float ns = (float)samples;
+        out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
+        // queries the reference would have run: it re-traces the primary ray for every sample
+        aux_rays[pix] = cnt.rays + (any_rays ? samples - 1u : 0u);
+    }
+
+    uint32_t r = wave_sum_u32(valid ? cnt.rays : 0u);
+    if (lane == 0) atomicAdd(&counters->rays, (unsigned long long)r);
+    if (STATS) {
+        uint32_t a = wave_sum_u32(cnt.xforms), b = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
+                 d = wave_sum_u32(cnt.shades);
+        if (lane == 0) {
+            atomicAdd(&counters->xforms, (unsigned long long)a);
+            atomicAdd(&counters->box_tests, (unsigned long long)b);
+            atomicAdd(&counters->tri_tests, (unsigned long long)c);
+            atomicAdd(&counters->shades, (unsigned long long)d);
+        }
+    }
+}
+
+// ---- hit_all for a batch of rays (the query stage on its own) -----------------------
+struct DRay {
+    float pos[3];
+    float dir[3];
+};
+struct DHit {
+    uint32_t object, triangle, flat_id;
+    float t;
+    float p[3], n[3], uv[2];
+};
+
+template <bool TLAS>
+__global__ __launch_bounds__(256) void k_query(SceneView sc, uint32_t stack_depth, const DRay* __restrict__ rays,
+                                               uint32_t n_rays, DHit* __restrict__ hits) {
+    extern __shared__ uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    LdsStack stk;
+    stk.base = &s_stack[wave * stack_depth * 64 + lane];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n_rays;
+    v3 ro = V3(0, 0, 0), rd = V3(0, 0, 1);
+    if (valid) {
+        ro = V3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
+        rd = V3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+    }
+    LaneCounters cnt = {0, 0, 0, 0, 0};
+    Best b;
+    closest_hit<TLAS, false>(sc, ro, rd, valid, b, stk, cnt);
+    if (!valid) return;
+    HitInfo h = finalize_hit(sc, ro, rd, b);
+    DHit o;
+    o.object = b.obj;
+    o.t = b.t;
+    if (b.obj != PT_NONE) {
+        o.triangle = b.tri;
+        o.flat_id = sc.objects[b.obj].tri_base + b.tri;
+    } else {
+        o.triangle = PT_NONE;
+        o.flat_id = PT_NONE;
+    }
+    o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+    o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
+    o.uv[0] = h.u; o.uv[1] = h.v;
+    hits[i] = o;
+}
+
+// acc += frame; out = acc / n_frames  (radiance accumulation across frames; RGB only, A stays 1)
+__global__ void k_accumulate(float4* __restrict__ acc, float4* __restrict__ img, uint32_t n_pixels, float n_frames) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 a = acc[i], f = img[i];
+    a.x += f.x; a.y += f.y; a.z += f.z; a.w = 1.0f;
+    acc[i] = a;
+    img[i] = make_float4(pt_div(a.x, n_frames), pt_div(a.y, n_frames), pt_div(a.z, n_frames), 1.0f);
+}
