@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one step = one frame of the path tracer over one synthetic scene.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload boxes] [--no-cpu-baseline]
+
+N = 1 renders BASELINE.json configs[1]: the examples/boxes.rs scene at 1920x1080, 64 spp, 10 bounces,
+scene and image resident in HBM. For N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank renders the same frame as an independent virtual frame (its own `time`, hence its own per-pixel
+seeds, exactly how the reference de-correlates successive frames) and the radiance buffers are summed
+with one RCCL all-reduce per step: N x 64 spp per step, per-GPU work fixed (weak scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from path_tracing_amd import abi, scenes  # noqa: E402
+
+# Algorithmic work per unit (flop, bytes): ray-object transform, BVH node box test, ray-triangle test,
+# hit-record construction, scatter evaluation. Counted from the reference's expressions
+# (src/query.wgsl:73-74, :127-147, :95-109, :113-120; src/raytrace.wgsl:157-203).
+WORK = {"xforms": (33 + 25, 96 + 24), "box_tests": (25, 32), "tri_tests": (53, 36), "hits": (73, 60), "shades": (200, 64)}
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 (256 CU x 128 lanes x 2 flop x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    "boxes": ("examples/boxes.rs scene, 1920x1080, 64 spp, 10 bounces", lambda: scenes.boxes(1920, 1080, 64, 10)),
+    "cornell": ("examples/cornellbox.rs scene, 512x512, 16 spp, 10 bounces", lambda: scenes.cornell_box(512, 512, 16, 10)),
+    "scene_glb_textured": ("assets/scene.glb + example.png texture, 1920x1080, 256 spp", lambda: scenes.scene_glb_textured(1920, 1080, 256, 10)),
+    "instanced_boxes": ("83,334 instanced cubes (1,000,008 triangles), 1920x1080, 256 spp", lambda: scenes.instanced_boxes(83334, 1920, 1080, 256, 10)),
+    "cornell_4k": ("Cornell box 3840x2160, 4096 spp", lambda: scenes.cornell_4k(4096)),
+}
+
+
+def virtual_frame_time(rank: int) -> float:
+    """time + 1 is the seed multiplier (src/raytrace.wgsl:210). Rank 0 uses time = 0 (seed = pixel coordinates);
+    further ranks use k + 0.5 so that (x + 0.5) * (time + 1) never sits on an integer boundary."""
+    return 0.0 if rank == 0 else float(rank) + 0.5
+
+
+def cpu_baseline(scene, spp: int):
+    """The CPU restatement (oracle/) timed on this host: same scene and resolution, `spp` samples."""
+    from tests.oracle_lib import load_oracle, oracle_render
+    lib = load_oracle()
+    threads = int(lib.pto_num_threads())
+    threads = max(1, min(threads, 16, os.cpu_count() or 1))
+    frame = scene.frame(samples=spp)
+    t0 = time.perf_counter()
+    r = oracle_render(scene, frame, threads=threads)
+    dt = time.perf_counter() - t0
+    rays = int(r["ray_count"].astype(np.uint64).sum())
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{scene.name} {frame.width}x{frame.height}, {spp} of {scene.samples} spp, all bounces "
+                      f"({rays} rays in {dt:.2f} s; the restatement re-traces the primary ray for every sample as the reference does)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="boxes", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (invalidates the headline config)")
+    ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    desc, make = WORKLOADS[args.workload]
+    scene = make()
+    if args.spp:
+        scene.samples = args.spp
+    frame = scene.frame(time=virtual_frame_time(rank))
+    W, H = frame.width, frame.height
+
+    ctx = abi.Context(device=local_rank)
+    ctx.upload_scene(scene)
+    out = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream(device)
+
+    def step():
+        ctx.render_device(frame, out.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+            out.mul_(1.0 / world)
+
+    # detailed work counters from one untimed pass (slower kernel variant)
+    ctx.set_stats_detail(True)
+    ctx.render_device(frame, out.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(device)
+    detail = ctx.stats()
+    ctx.set_stats_detail(False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+
+    # kernel durations (HIP events recorded by the library on the launch stream), one step at a time
+    kernel_ms = []
+    for _ in range(args.steps):
+        ctx.render_device(frame, out.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(device)
+        kernel_ms.append(ctx.stats()["trace_ms"])
+    st = ctx.stats()
+    mean_img = float(out[..., :3].mean().item())
+
+    rays_local = int(st["rays"])
+    t_max = dt
+    rays_total = rays_local
+    if world > 1:
+        buf = torch.tensor([dt, float(rays_local), float(st["rays_reference"]), float(st["paths"])], dtype=torch.float64, device=device)
+        tmax = buf.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        t_max = float(tmax[0].item())
+        rays_total = int(buf[1].item())
+        rays_ref_total = int(buf[2].item())
+        paths_total = int(buf[3].item())
+    else:
+        rays_ref_total = int(st["rays_reference"])
+        paths_total = int(st["paths"])
+
+    if rank == 0:
+        ms_per_step = t_max / args.steps * 1e3
+        value = rays_total / (t_max / args.steps) / 1e6
+        k_ms = float(np.mean(kernel_ms))
+        flops = sum(detail[k] * WORK[k][0] for k in WORK)
+        abytes = sum(detail[k] * WORK[k][1] for k in WORK) + W * H * 16
+        achieved_tflops = flops / (k_ms * 1e-3) / 1e12
+        traffic = None
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mrays/s (all bounces) at 1080p" if H == 1080 else "Mrays/s (all bounces)",
+            "value": round(value, 1),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "scene": scene.name, "width": W, "height": H, "spp_per_gpu": scene.samples,
+                       "bounces": scene.bounces, "objects": int(scene.objects.size), "triangles": scene.n_triangles,
+                       "multi_gpu": "one virtual frame per GPU + RCCL all-reduce(sum) of the f32 radiance buffer" if world > 1 else "single GPU"},
+            "rays_per_step": rays_total,
+            "rays_definition": "closest-hit queries executed; the primary ray of a pixel is identical for all of its samples "
+                               "(src/raytrace.wgsl:223) and is traced once, the reference would trace rays_reference_per_step",
+            "rays_reference_per_step": rays_ref_total,
+            "mrays_reference_equiv_per_s": round(rays_ref_total / (t_max / args.steps) / 1e6, 1),
+            "samples_per_s": round(paths_total / (t_max / args.steps), 1),
+            "image_mean": round(mean_img, 6),
+            "roofline": {"bound": "valu", "kernel": "k_render", "achieved": round(achieved_tflops, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VALU_TFLOPS, 5),
+                         "traffic": traffic,
+                         "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": int(flops),
+                         "algorithmic_bytes_per_launch": int(abytes),
+                         "hbm": {"achieved_GBs": round(abytes / (k_ms * 1e-3) / 1e9, 2), "peak_GBs": PEAK_HBM_GBS,
+                                 "frac": round(abytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)},
+                         "counts": {k: int(detail[k]) for k in WORK}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_spp, scene.samples))
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -259,6 +259,7 @@ typedef struct PtStats {
     uint64_t box_tests;     /* BVH node-child box tests                          */
     uint64_t tri_tests;     /* ray-triangle tests                               */
     uint64_t shades;        /* scatter evaluations (calculate_brdf)             */
+    uint64_t hits;          /* queries that found a surface (hit_record built)  */
     double trace_ms;        /* device time of the trace kernel(s), HIP events   */
     double build_ms;        /* device time of the last TLAS build                */
     uint32_t trace_launches;/* kernel launches that trace_ms covers              */

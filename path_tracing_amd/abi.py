@@ -77,7 +77,7 @@ class PtConfig(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rays_reference", C.c_uint64), ("paths", C.c_uint64),
                 ("xforms", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("shades", C.c_uint64), ("trace_ms", C.c_double), ("build_ms", C.c_double),
+                ("shades", C.c_uint64), ("hits", C.c_uint64), ("trace_ms", C.c_double), ("build_ms", C.c_double),
                 ("trace_launches", C.c_uint32), ("accel_used", C.c_uint32)]
 
     def as_dict(self):

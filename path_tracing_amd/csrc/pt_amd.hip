@@ -521,6 +521,7 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.box_tests = c.box_tests;
     ctx->stats.tri_tests = c.tri_tests;
     ctx->stats.shades = c.shades;
+    ctx->stats.hits = c.hits;
     ctx->stats.paths = ctx->last_paths;
     ctx->stats.rays_reference = c.rays + ctx->last_primary;
     ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u);

@@ -114,5 +114,6 @@ struct DCounters {
     unsigned long long box_tests;
     unsigned long long tri_tests;
     unsigned long long shades;
-    unsigned long long _pad[3];
+    unsigned long long hits;
+    unsigned long long _pad[2];
 };

@@ -28,7 +28,7 @@ struct HitInfo {
 };
 
 struct LaneCounters {
-    uint32_t rays, xforms, box_tests, tri_tests, shades;
+    uint32_t rays, xforms, box_tests, tri_tests, shades, hits;
 };
 
 // Per-lane traversal stack in LDS: entry [level][lane], so a wave's push/pop touches 64 consecutive banks.
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_render(SceneView sc, FrameParams fp, ui
     const uint32_t px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
     const bool valid = px < fp.width && py < fp.height;
 
-    LaneCounters cnt = {0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
 
     // fullscreen triangle at the pixel centre; src/raytrace.wgsl:210-217
     const float W = (float)fp.width, H = (float)fp.height;
@@ -402,6 +402,7 @@ __global__ __launch_bounds__(256) void k_render(SceneView sc, FrameParams fp, ui
         closest_hit<TLAS, STATS>(sc, origin, dir0, valid, pb, stk, cnt);
         if (valid) {
             cnt.rays = 1;
+            if (STATS && pb.obj != PT_NONE) cnt.hits++;
             hp = finalize_hit(sc, origin, dir0, pb);
         }
     }
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(256) void k_render(SceneView sc, FrameParams fp, ui
                 closest_hit<TLAS, STATS>(sc, rpos, rdir, need, b, stk, cnt);
                 if (need) {
                     cnt.rays++;
+                    if (STATS && b.obj != PT_NONE) cnt.hits++;
                     h = finalize_hit(sc, rpos, rdir, b);
                 }
             }
@@ -489,8 +491,9 @@ __global__ __launch_bounds__(256) void k_render(SceneView sc, FrameParams fp, ui
     if (lane == 0) atomicAdd(&counters->rays, (unsigned long long)r);
     if (STATS) {
         uint32_t a = wave_sum_u32(cnt.xforms), b = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
-                 d = wave_sum_u32(cnt.shades);
+                 d = wave_sum_u32(cnt.shades), e = wave_sum_u32(cnt.hits);
         if (lane == 0) {
+            atomicAdd(&counters->hits, (unsigned long long)e);
             atomicAdd(&counters->xforms, (unsigned long long)a);
             atomicAdd(&counters->box_tests, (unsigned long long)b);
             atomicAdd(&counters->tri_tests, (unsigned long long)c);
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void k_query(SceneView sc, uint32_t stack_dept
         ro = V3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
         rd = V3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
     }
-    LaneCounters cnt = {0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
     Best b;
     closest_hit<TLAS, false>(sc, ro, rd, valid, b, stk, cnt);
     if (!valid) return;

@@ -1,0 +1,347 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the committed golden vectors, against
+the CPU restatement on the same seeded inputs, and - at full benchmark sizes - through properties that do not
+need the checker (acceleration structure on/off bit-identity, partition union, determinism, ray accounting).
+
+Bar: bit-exact for primary-hit object / flat triangle ids, hit distances, ray counts; the image is required to
+agree within relative RMSE 1e-3 (the tolerance the goal states) and, because both sides use the same fixed f32
+evaluation rules, is additionally expected to be bit-identical.
+"""
+import numpy as np
+import pytest
+
+from path_tracing_amd import abi, scenes
+from tests.oracle_lib import oracle_query, oracle_render
+from tools.make_golden import golden_scenes
+
+pytestmark = pytest.mark.gpu
+
+ACCELS = [abi.PT_ACCEL_BRUTE, abi.PT_ACCEL_AUTO, abi.PT_ACCEL_BVH]
+RRMSE_TOL = 1e-3
+
+
+def rrmse(a, b):
+    a, b = a[..., :3].astype(np.float64), b[..., :3].astype(np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30)))
+
+
+def render_all(scene, frame, accel=abi.PT_ACCEL_AUTO, tie=abi.PT_TIE_REFERENCE):
+    with abi.Context(accel=accel, tie_rule=tie) as ctx:
+        ctx.upload_scene(scene)
+        img = ctx.render(frame)
+        out = dict(image=img, primary_object=ctx.read_aux(abi.PT_AUX_PRIMARY_OBJECT),
+                   primary_flat_id=ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID), primary_t=ctx.read_aux(abi.PT_AUX_PRIMARY_T),
+                   ray_count=ctx.read_aux(abi.PT_AUX_RAY_COUNT), stats=ctx.stats(), accel=ctx.check_accel())
+    return out
+
+
+def assert_same(got, want_img, want_obj, want_flat, want_t_bits, want_rays):
+    assert np.array_equal(got["primary_object"], want_obj)
+    assert np.array_equal(got["primary_flat_id"], want_flat)
+    assert np.array_equal(got["primary_t"].view(np.uint32), want_t_bits)
+    assert np.array_equal(got["ray_count"], want_rays)
+    assert rrmse(got["image"], want_img) <= RRMSE_TOL
+    assert np.array_equal(got["image"].view(np.uint32), want_img.view(np.uint32)), "image not bit-identical"
+    assert got["accel"]["errors"] == 0
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+@pytest.mark.parametrize("name", ["cornell", "boxes", "scene_glb_textured", "texture_cube", "instanced_boxes"])
+def test_golden_frames(name, accel, golden_dir):
+    scene, _ = golden_scenes()[name]
+    g = np.load(golden_dir / f"frame_{name}.npz")
+    got = render_all(scene, scene.frame(), accel)
+    assert_same(got, g["image_bits"].view(np.float32), g["primary_object"], g["primary_flat_id"], g["primary_t_bits"], g["ray_count"])
+    assert got["stats"]["rays_reference"] == int(g["ray_count"].astype(np.uint64).sum())
+
+
+def test_golden_frame_nonzero_time(golden_dir):
+    scene = scenes.cornell_box(64, 64, 4, 10)
+    g = np.load(golden_dir / "frame_cornell_time0p5.npz")
+    got = render_all(scene, scene.frame(time=0.5))
+    assert np.array_equal(got["image"].view(np.uint32), g["image_bits"])
+    assert np.array_equal(got["ray_count"], g["ray_count"])
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_golden_ray_hits(accel, golden_dir):
+    g = np.load(golden_dir / "ray_hits.npz")
+    scs = {"cornell": scenes.cornell_box(64, 64, 1, 1), "boxes": scenes.boxes(64, 64, 1, 1),
+           "scene_glb_textured": scenes.scene_glb_textured(64, 64, 1, 1)}
+    for name, scene in scs.items():
+        rays = np.ascontiguousarray(g[name + "_rays"]).view(abi.RAY_DT).reshape(-1)
+        with abi.Context(accel=accel) as ctx:
+            ctx.upload_scene(scene)
+            hits = ctx.query(rays)
+        want = g[name + "_hits"]
+        got = hits.view(np.uint32).reshape(-1, 12)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, f"{name}: {bad.size} rays differ, first {bad[:5]}"
+
+
+@pytest.mark.parametrize("name,kw,time", [
+    ("cornell", dict(width=128, height=128, samples=16), 0.0),
+    ("cornell", dict(width=61, height=37, samples=3), 1.5),       # ragged size: partial 8x8 tiles
+    ("boxes", dict(width=160, height=90, samples=16), 0.0),
+    ("scene_glb_textured", dict(width=120, height=68, samples=4), 2.5),
+])
+def test_live_oracle_parity(name, kw, time):
+    scene = scenes.CONFIGS[name](**kw)
+    frame = scene.frame(time=time)
+    ref = oracle_render(scene, frame)
+    for accel in (abi.PT_ACCEL_AUTO, abi.PT_ACCEL_BVH):
+        got = render_all(scene, frame, accel)
+        assert_same(got, ref["image"], ref["primary_object"], ref["primary_flat_id"], ref["primary_t"].view(np.uint32), ref["ray_count"])
+
+
+def materials_zoo():
+    """Every texture format (1-4 channels and an unsupported count), emissive / normal-map / metallic-roughness
+    textures, a non-square texture (row stride = height quirk), u = 1.0 reads one past the row."""
+    b = scenes.SceneBuilder()
+    g = np.random.Generator(np.random.PCG64(5))
+    t1 = b.add_texture(g.uniform(0.2, 1, 8 * 8 * 1), 8, 8, 1)
+    t2 = b.add_texture(g.uniform(0.2, 1, 8 * 4 * 2), 8, 4, 2)
+    t3 = b.add_texture(g.uniform(0.2, 1, 4 * 8 * 3), 4, 8, 3)
+    t4 = b.add_texture(g.uniform(0.2, 1, 16 * 16 * 4), 16, 16, 4)
+    t5 = b.add_texture(g.uniform(0.2, 1, 4 * 4 * 5), 4, 4, 5)
+    tn = b.add_texture(g.uniform(0.5, 1, 8 * 8 * 3), 8, 8, 3)
+    cube = b.add_mesh(*scenes.cube_mesh(1.0))
+    plane = b.add_mesh(*scenes.plane_mesh((0, 1, 0), 4.0))
+    mats = [b.add_material(albedo=(1, 1, 1), albedo_texture=t1, roughness=0.3),
+            b.add_material(albedo=(0.9, 0.9, 0.9), albedo_texture=t2, roughness=0.8),
+            b.add_material(albedo=(1, 1, 1), albedo_texture=t3, normal_map_texture=tn, roughness=1.0),
+            b.add_material(albedo=(0, 0, 0), emissive=(9, 9, 9), emissive_texture=t4),
+            b.add_material(albedo=(0.8, 0.7, 0.6), albedo_texture=t5, metallic_roughness_texture=t1, roughness=0.0),
+            b.add_material(albedo=(0.7, 0.7, 0.7), albedo_texture=t4, roughness=0.6)]
+    for i in range(5):
+        b.add_object(cube, mats[i], scenes.translation(-3.0 + 1.5 * i, 0.0, 0.0) @ scenes.rotation_y(0.3 * i) @ scenes.scaling(1, 1 + 0.1 * i, 1))
+    b.add_object(plane, mats[5], scenes.translation(0, -0.7, 0))
+    return b.build("zoo", scenes.Camera((0.5, 2.5, 5.0), (0, 0, 0)), sky_color=(0.3, 0.4, 0.5), width=96, height=64, samples=4, bounces=6)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_materials_zoo_against_oracle(accel):
+    scene = materials_zoo()
+    frame = scene.frame()
+    ref = oracle_render(scene, frame)
+    got = render_all(scene, frame, accel)
+    assert_same(got, ref["image"], ref["primary_object"], ref["primary_flat_id"], ref["primary_t"].view(np.uint32), ref["ray_count"])
+
+
+def test_query_random_rays_against_oracle():
+    scene = scenes.instanced_boxes(n_objects=3000, width=8, height=8, samples=1, extent=10.0)
+    g = np.random.Generator(np.random.PCG64(99))
+    n = 4096
+    rays = np.zeros(n, dtype=abi.RAY_DT)
+    rays["pos"] = g.uniform(-14, 14, (n, 3)).astype(np.float32)
+    d = g.normal(size=(n, 3))
+    rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["dir"][:64, 0] = 0.0      # axis-parallel components (infinite reciprocals)
+    rays["dir"][64:128, 1] = 0.0
+    want = oracle_query(scene, rays)
+    for accel in ACCELS:
+        with abi.Context(accel=accel) as ctx:
+            ctx.upload_scene(scene)
+            got = ctx.query(rays)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"accel {accel}"
+    assert (want["object"] != abi.PT_U32_MAX).sum() > 500
+
+
+def test_tie_rules():
+    b = scenes.SceneBuilder()
+    m = b.add_mesh(*scenes.plane_mesh((0, 1, 0), 1.0))
+    mat = b.add_material()
+    b.add_object(m, mat)
+    b.add_object(m, mat)
+    scene = b.build("tie", scenes.Camera((0, 3, 0), (0, 0, 0)))
+    rays = np.zeros(2, dtype=abi.RAY_DT)
+    rays["pos"] = [(0.25, 2.0, 0.25), (0.5, 2.0, -0.25)]
+    rays["dir"] = [(0, -1, 0)] * 2
+    want = oracle_query(scene, rays)
+    for accel in ACCELS:
+        with abi.Context(accel=accel, tie_rule=abi.PT_TIE_REFERENCE) as ctx:
+            ctx.upload_scene(scene)
+            h = ctx.query(rays)
+        assert np.array_equal(h.view(np.uint32), want.view(np.uint32))
+        assert list(h["object"]) == [1, 1] and h["triangle"][0] == 1
+        with abi.Context(accel=accel, tie_rule=abi.PT_TIE_LOWEST) as ctx:
+            ctx.upload_scene(scene)
+            h = ctx.query(rays)
+        assert list(h["object"]) == [0, 0] and h["triangle"][0] == 0
+        assert np.array_equal(h["t"], want["t"])
+
+
+# ---- full benchmark sizes: properties that need no checker -----------------------------------
+def test_boxes_1080p_accel_invariance_and_accounting():
+    scene = scenes.boxes(1920, 1080, 64, 10)
+    frame = scene.frame()
+    a = render_all(scene, frame, abi.PT_ACCEL_BRUTE)
+    b = render_all(scene, frame, abi.PT_ACCEL_BVH)
+    c = render_all(scene, frame, abi.PT_ACCEL_BRUTE)
+    for other in (b, c):  # acceleration structure on/off and run-to-run: bit-identical
+        assert np.array_equal(a["image"].view(np.uint32), other["image"].view(np.uint32))
+        assert np.array_equal(a["primary_flat_id"], other["primary_flat_id"])
+        assert np.array_equal(a["ray_count"], other["ray_count"])
+    assert np.all(a["image"][..., 3] == 1.0) and np.isfinite(a["image"]).all()
+    st = a["stats"]
+    assert st["paths"] == 1920 * 1080 * 64
+    assert st["rays_reference"] == int(a["ray_count"].astype(np.uint64).sum())
+    assert st["rays"] == st["rays_reference"] - 1920 * 1080 * 63
+    # a crop of the same frame against the CPU restatement
+    rect = (900, 500, 932, 524)
+    ref = oracle_render(scene, frame, rect=rect)
+    x0, y0, x1, y1 = rect
+    assert np.array_equal(a["image"][y0:y1, x0:x1].view(np.uint32), ref["image"].view(np.uint32))
+    assert np.array_equal(a["primary_flat_id"][y0:y1, x0:x1], ref["primary_flat_id"])
+
+
+def test_million_triangles_tlas_vs_loop_and_oracle_crop():
+    scene = scenes.instanced_boxes(83334, 1920, 1080, 1, 10)
+    assert scene.n_triangles == 1000008
+    frame = scene.frame(width=480, height=270)
+    a = render_all(scene, frame, abi.PT_ACCEL_AUTO)
+    assert a["accel"]["errors"] == 0 and a["accel"]["tlas_depth"] > 0
+    b = render_all(scene, frame, abi.PT_ACCEL_BRUTE)
+    assert np.array_equal(a["image"].view(np.uint32), b["image"].view(np.uint32))
+    assert np.array_equal(a["primary_flat_id"], b["primary_flat_id"])
+    assert np.array_equal(a["primary_t"].view(np.uint32), b["primary_t"].view(np.uint32))
+    assert np.array_equal(a["ray_count"], b["ray_count"])
+    rect = (232, 128, 248, 140)
+    ref = oracle_render(scene, frame, rect=rect)
+    x0, y0, x1, y1 = rect
+    assert np.array_equal(a["image"][y0:y1, x0:x1].view(np.uint32), ref["image"].view(np.uint32))
+    assert np.array_equal(a["primary_flat_id"][y0:y1, x0:x1], ref["primary_flat_id"])
+    # full 1080p through the TLAS: finite, alpha 1, most pixels see geometry
+    full = render_all(scene, scene.frame(), abi.PT_ACCEL_AUTO)
+    assert np.isfinite(full["image"]).all() and np.all(full["image"][..., 3] == 1.0)
+    assert (full["primary_object"] != abi.PT_U32_MAX).mean() > 0.3
+
+
+def test_partition_union_equals_full_frame():
+    scene = scenes.boxes(200, 120, 4, 10)
+    full = render_all(scene, scene.frame())
+    acc = np.zeros_like(full["image"])
+    rays = 0
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        for k in range(3):
+            part = ctx.render(scene.frame(part_index=k, part_count=3))
+            owned = part[..., 3] == 1.0
+            assert not np.any(owned & (acc[..., 3] == 1.0))  # disjoint
+            acc += part
+            rays += ctx.stats()["rays"]
+    assert np.array_equal(acc.view(np.uint32), full["image"].view(np.uint32))
+    assert rays == full["stats"]["rays"]
+
+
+def test_accumulation_is_mean_of_frames():
+    scene = scenes.cornell_box(64, 64, 4, 10)
+    times = [0.0, 1.5, 2.5]
+    frames = [oracle_render(scene, scene.frame(time=t))["image"] for t in times]
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        outs = []
+        for i, t in enumerate(times):
+            flags = abi.PT_FRAME_ACCUMULATE | (abi.PT_FRAME_RESET if i == 0 else 0)
+            outs.append(ctx.render(scene.frame(time=t, flags=flags)))
+    acc = np.zeros_like(frames[0][..., :3])
+    for i, f in enumerate(frames):
+        acc = acc + f[..., :3]
+        want = acc / np.float32(i + 1)
+        assert np.array_equal(outs[i][..., :3].view(np.uint32), want.view(np.uint32))
+        assert np.all(outs[i][..., 3] == 1.0)
+
+
+# ---- edge cases and error behaviour -------------------------------------------------------------
+def test_empty_scene_renders_sky():
+    b = scenes.SceneBuilder()
+    scene = b.build("empty", scenes.Camera((3, 3, 3), (0, 0, 0)), sky_color=(0.1, 0.2, 0.4), width=40, height=24, samples=3, bounces=5)
+    for accel in ACCELS:
+        got = render_all(scene, scene.frame(), accel)
+        ref = oracle_render(scene, scene.frame())
+        assert np.array_equal(got["image"].view(np.uint32), ref["image"].view(np.uint32))
+        assert np.all(got["primary_object"] == abi.PT_U32_MAX) and np.all(got["ray_count"] == 3)
+
+
+def test_zero_bounces_and_zero_samples():
+    scene = scenes.boxes(32, 16, 3, 4)
+    got = render_all(scene, scene.frame(bounces=0))
+    assert got["stats"]["rays"] == 0 and np.all(got["image"][..., :3] == 0) and np.all(got["ray_count"] == 0)
+    got = render_all(scene, scene.frame(samples=0))
+    assert np.all(np.isnan(got["image"][..., :3])) and got["stats"]["rays"] == 0
+
+
+def test_mesh_without_triangles_and_single_triangle():
+    b = scenes.SceneBuilder()
+    tri = b.add_mesh([(0, 0, 0), (1, 0, 0), (0, 0, -1)], [(0, 1, 0)] * 3, [(0, 0), (1, 0), (0, 1)], [0, 1, 2])
+    empty = b.add_mesh([(0, 0, 0)], [(0, 1, 0)], [(0, 0)], [])
+    mat = b.add_material(albedo=(0.5, 0.5, 0.5))
+    b.add_object(empty, mat)
+    b.add_object(tri, mat, scenes.scaling(2, 2, 2))
+    scene = b.build("one", scenes.Camera((1, 4, 1), (0.5, 0, -0.5)), sky_color=(1, 1, 1), width=48, height=48, samples=2, bounces=3)
+    ref = oracle_render(scene, scene.frame())
+    for accel in ACCELS:
+        got = render_all(scene, scene.frame(), accel)
+        assert_same(got, ref["image"], ref["primary_object"], ref["primary_flat_id"], ref["primary_t"].view(np.uint32), ref["ray_count"])
+    assert (ref["primary_object"] == 1).sum() > 10
+
+
+def test_error_codes():
+    scene = scenes.cornell_box(16, 16, 1, 2)
+    with abi.Context() as ctx:
+        with pytest.raises(abi.PtError) as e:
+            ctx.render(scene.frame())
+        assert e.value.code == abi.PT_ERR_NOT_READY
+        bad = scene.indices.copy()
+        bad[3] = 1000
+        with pytest.raises(abi.PtError) as e:
+            ctx.upload_meshes(scene.meshes, bad, scene.vertices)
+        assert e.value.code == abi.PT_ERR_INVALID_SCENE
+        badm = scene.meshes.copy()
+        badm["tri_count"][0] = 50
+        with pytest.raises(abi.PtError) as e:
+            ctx.upload_meshes(badm, scene.indices, scene.vertices)
+        assert e.value.code == abi.PT_ERR_INVALID_SCENE
+        nanv = scene.vertices.copy()
+        nanv["position"][2, 1] = np.nan
+        with pytest.raises(abi.PtError) as e:
+            ctx.upload_meshes(scene.meshes, scene.indices, nanv)
+        assert e.value.code == abi.PT_ERR_INVALID_SCENE
+        ctx.upload_meshes(scene.meshes, scene.indices, scene.vertices)
+        badmat = scene.materials.copy()
+        badmat["albedo_texture"][0] = 3
+        with pytest.raises(abi.PtError) as e:
+            ctx.upload_materials(badmat, scene.textures, scene.texture_data)
+        assert e.value.code == abi.PT_ERR_INVALID_SCENE
+        ctx.upload_materials(scene.materials, scene.textures, scene.texture_data)
+        bado = scene.objects.copy()
+        bado["mesh"][1] = 77
+        with pytest.raises(abi.PtError) as e:
+            ctx.upload_objects(bado)
+        assert e.value.code == abi.PT_ERR_INVALID_SCENE
+        bado = scene.objects.copy()
+        bado["mat"][1] = 77
+        ctx.upload_objects(bado)  # materials are checked when the frame is rendered
+        with pytest.raises(abi.PtError) as e:
+            ctx.render(scene.frame())
+        assert e.value.code == abi.PT_ERR_INVALID_SCENE
+        ctx.upload_objects(scene.objects)
+        with pytest.raises(abi.PtError) as e:
+            ctx.render(scene.frame(part_index=2, part_count=2))
+        assert e.value.code == abi.PT_ERR_INVALID_ARGUMENT
+        img = ctx.render(scene.frame())  # the context is still usable after errors
+        assert np.isfinite(img).all()
+
+
+def test_reupload_order_independent():
+    scene = scenes.boxes(64, 36, 2, 4)
+    ref = render_all(scene, scene.frame())
+    with abi.Context() as ctx:
+        ctx.upload_objects(scene.objects)      # objects first, meshes later
+        ctx.upload_materials(scene.materials, scene.textures, scene.texture_data)
+        ctx.upload_meshes(scene.meshes, scene.indices, scene.vertices)
+        img = ctx.render(scene.frame())
+        assert np.array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
+        other = scenes.cornell_box(64, 36, 2, 4)
+        ctx.upload_scene(other)                # replace everything on a live context
+        img2 = ctx.render(other.frame())
+    assert np.array_equal(img2.view(np.uint32), render_all(other, other.frame())["image"].view(np.uint32))
