@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile.sh into profiles/<tag>_summary.json (+ kernel stats CSV copy).
+
+    python tools/summarize_profile.py <tag> [--kernel k_render] [--workload boxes]
+
+Per-launch averages over the dispatches of the chosen kernel:
+  duration from --kernel-trace; SQ counters; HBM traffic from FETCH_SIZE / WRITE_SIZE with the gfx950
+  correction for reads (FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams: doubled for the
+  upper bound, both figures are recorded). FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KiB.
+Also updates profiles/traffic.json, which bench.py reads for roofline.traffic.
+"""
+import argparse
+import csv
+import glob
+import json
+import shutil
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def read_counters(d, kernel):
+    files = glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True)
+    per = defaultdict(lambda: defaultdict(float))   # counter -> dispatch -> value
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if kernel in row["Kernel_Name"] and "true>" not in row["Kernel_Name"].split("(")[0].replace("false, true", "true>"):
+                    per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    return {c: (sum(v.values()) / len(v), len(v)) for c, v in per.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--kernel", default="k_render")
+    ap.add_argument("--workload", default="boxes")
+    args = ap.parse_args()
+    src = ROOT / "gpurun_out" / f"prof_{args.tag}"
+    dst = ROOT / "profiles"
+    dst.mkdir(exist_ok=True)
+    out = {"tag": args.tag, "kernel": args.kernel, "workload": args.workload}
+
+    stats = glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], dst / f"{args.tag}_kernel_stats.csv")
+        with open(stats[0]) as fh:
+            rows = list(csv.DictReader(fh))
+        out["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                "pct": float(r["Percentage"])} for r in rows[:8]]
+        for r in rows:
+            if args.kernel in r["Name"] and "<false, true>" not in r["Name"] and "<true, true>" not in r["Name"]:
+                out["avg_kernel_ms"] = float(r["AverageNs"]) / 1e6
+                out["calls"] = int(r["Calls"])
+                break
+    trace = glob.glob(str(src / "trace" / "**" / "*kernel_trace.csv"), recursive=True)
+    if trace:
+        with open(trace[0]) as fh:
+            for r in csv.DictReader(fh):
+                if args.kernel in r["Kernel_Name"]:
+                    out["launch"] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                                                       "Workgroup_Size_X", "Grid_Size_X")}
+                    break
+    counters = {}
+    for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+        for c, (avg, n) in read_counters(src / sub, args.kernel).items():
+            counters[c] = avg
+    out["counters_per_launch"] = counters
+    if "SQ_WAVE_CYCLES" in counters and counters.get("SQ_WAVE_CYCLES"):
+        wc = counters["SQ_WAVE_CYCLES"]
+        out["derived"] = {
+            "valu_active_share_of_wave_cycles": counters.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+            "any_inst_active_share": counters.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+            "wait_inst_any_share": counters.get("SQ_WAIT_INST_ANY", 0) / wc,
+            "valu_insts_per_wave": counters.get("SQ_INSTS_VALU", 0) / max(counters.get("SQ_WAVES", 1), 1),
+            "salu_insts_per_wave": counters.get("SQ_INSTS_SALU", 0) / max(counters.get("SQ_WAVES", 1), 1),
+        }
+        if "SQ_THREAD_CYCLES_VALU" in counters and counters.get("SQ_ACTIVE_INST_VALU"):
+            # lanes active per VALU instruction (64 = no divergence)
+            out["derived"]["valu_lane_utilisation"] = counters["SQ_THREAD_CYCLES_VALU"] / (counters["SQ_ACTIVE_INST_VALU"] * 64.0) / 4.0 * 4.0
+    if "FETCH_SIZE" in counters or "WRITE_SIZE" in counters:
+        fetch_kib = counters.get("FETCH_SIZE", 0.0)
+        write_kib = counters.get("WRITE_SIZE", 0.0)
+        hbm = {"fetch_bytes_raw": fetch_kib * 1024, "fetch_bytes_corrected_x2": fetch_kib * 2048, "write_bytes": write_kib * 1024}
+        hbm["hbm_bytes_per_launch"] = hbm["fetch_bytes_corrected_x2"] + hbm["write_bytes"]
+        if "avg_kernel_ms" in out:
+            hbm["GBs"] = hbm["hbm_bytes_per_launch"] / (out["avg_kernel_ms"] * 1e-3) / 1e9
+        out["hbm"] = hbm
+        tf = dst / "traffic.json"
+        cur = json.loads(tf.read_text()) if tf.exists() else {}
+        cur[args.workload] = {"hbm_bytes_per_launch": hbm["hbm_bytes_per_launch"], "tag": args.tag}
+        tf.write_text(json.dumps(cur, indent=1) + "\n")
+    (dst / f"{args.tag}_summary.json").write_text(json.dumps(out, indent=1) + "\n")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
