@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -73,6 +74,9 @@ struct pt_ctx {
     bool use_tlas = false;
     std::vector<PtObject> h_objects;  // kept so that a mesh re-upload can rebuild the instance data
 
+    uint32_t n_cus = 256;
+    uint32_t chunk_pixels = 64;   // see FrameParams::chunk
+    uint32_t refill_min = 0;      // see FrameParams::refill_min; 0 = choose per scene
     uint32_t aux_w = 0, aux_h = 0;
     uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
     bool stats_detail = false;
@@ -167,6 +171,9 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         pt_ctx* ctx = new pt_ctx();
         ctx->cfg = *cfg;
         ctx->device = cfg->device;
+        ctx->n_cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
+        if (const char* e = std::getenv("PT_AMD_REFILL_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_min = (uint32_t)v; }
+        if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; }
         std::snprintf(ctx->info, sizeof ctx->info, "pt_amd abi %d | %s %s | %d CUs | %d MHz | %.0f GiB", PT_ABI_VERSION, prop.name,
                       prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1073741824.0);
         hipError_t e = hipSetDevice(ctx->device);
@@ -497,6 +504,8 @@ SceneView make_view(const pt_ctx* ctx) {
     v.tri_attrs = ctx->d_attrs.as<DTriAttr>();
     v.blas_nodes = ctx->d_blas_nodes.as<BvhNode>();
     v.tlas_nodes = ctx->d_tlas_nodes.as<BvhNode>();
+    v.obj_lo = ctx->d_obj_lo.as<float4>();
+    v.obj_hi = ctx->d_obj_hi.as<float4>();
     v.materials = ctx->d_materials.as<DMaterial>();
     v.textures = ctx->d_textures.as<DTexture>();
     v.texture_data = ctx->d_texdata.as<float>();
@@ -504,6 +513,9 @@ SceneView make_view(const pt_ctx* ctx) {
     v.n_texture_data = ctx->n_texdata;
     v.tlas_root = ctx->tlas_root;
     v.tie_lowest = (ctx->cfg.tie_rule == PT_TIE_LOWEST) ? 1u : 0u;
+    v.cull_boxes = (ctx->cfg.accel == PT_ACCEL_BRUTE) ? 0u : 1u;
+    v._pad0 = 0;
+    v._pad1 = 0;
     return v;
 }
 
@@ -565,6 +577,17 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     fp.tiles_y = div_up(f->height, 8);
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     fp.n_local_tiles = (f->part_index < n_tiles) ? (n_tiles - f->part_index + pc - 1) / pc : 0u;
+    fp.chunk = ctx->chunk_pixels;
+    // few objects: keep a wave on one tile at a time (coherent candidates); many objects: keep every lane busy
+    fp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
+    {   // a stride near 0.618 * n that is coprime to n
+        uint32_t n = std::max(fp.n_local_tiles, 1u);
+        uint32_t sdr = (uint32_t)((double)n * 0.6180339887) | 1u;
+        if (std::getenv("PT_AMD_NO_SCATTER") || n < 8) sdr = 1;
+        auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
+        while (gcd(sdr, n) != 1) sdr += 2;
+        fp.tile_stride = sdr % n ? sdr % n : 1;
+    }
 
     PT_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
     if (pc > 1) {
@@ -576,24 +599,23 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     }
     SceneView sv = make_view(ctx);
     const uint32_t depth = stack_depth_needed(ctx);
-    const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t);
-    const uint32_t grid = div_up(fp.n_local_tiles, 4);
+    const size_t lds = (size_t)4 * (depth + PT_LANE_SLOTS) * 64 * sizeof(uint32_t);
+    const bool st = ctx->stats_detail;
+    // persistent waves: as many workgroups as fit on the chip at once (or fewer for small frames); they pull pixels
+    // from a counter until the frame is done
+    using RenderFn = void (*)(SceneView, FrameParams, uint32_t, float4*, uint32_t*, uint32_t*, float*, uint32_t*, DCounters*);
+    RenderFn fn = ctx->use_tlas ? (st ? k_render<true, true> : k_render<true, false>) : (st ? k_render<false, true> : k_render<false, false>);
+    int per_cu = 0;
+    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds));
+    if (per_cu < 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: the frame kernel does not fit on a compute unit with this traversal stack");
+    if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
+    const uint32_t resident = (uint32_t)per_cu * ctx->n_cus;
+    const uint32_t grid = std::min(div_up(fp.n_local_tiles, 4), resident);
     PT_HIP(ctx, hipEventRecord(ctx->ev0, s));
     if (grid) {
-        float4* o4 = reinterpret_cast<float4*>(out);
-        uint32_t* ao = ctx->d_aux_obj.as<uint32_t>();
-        uint32_t* af = ctx->d_aux_flat.as<uint32_t>();
-        float* at = ctx->d_aux_t.as<float>();
-        uint32_t* ar = ctx->d_aux_rays.as<uint32_t>();
-        DCounters* dc = ctx->d_counters.as<DCounters>();
-        const bool st = ctx->stats_detail;
-        if (ctx->use_tlas) {
-            if (st) k_render<true, true><<<grid, 256, lds, s>>>(sv, fp, depth, o4, ao, af, at, ar, dc);
-            else k_render<true, false><<<grid, 256, lds, s>>>(sv, fp, depth, o4, ao, af, at, ar, dc);
-        } else {
-            if (st) k_render<false, true><<<grid, 256, lds, s>>>(sv, fp, depth, o4, ao, af, at, ar, dc);
-            else k_render<false, false><<<grid, 256, lds, s>>>(sv, fp, depth, o4, ao, af, at, ar, dc);
-        }
+        fn<<<grid, 256, lds, s>>>(sv, fp, depth, reinterpret_cast<float4*>(out), ctx->d_aux_obj.as<uint32_t>(),
+                                  ctx->d_aux_flat.as<uint32_t>(), ctx->d_aux_t.as<float>(), ctx->d_aux_rays.as<uint32_t>(),
+                                  ctx->d_counters.as<DCounters>());
         PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, s));

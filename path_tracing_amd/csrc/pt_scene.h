@@ -85,13 +85,18 @@ struct SceneView {
     const DTriAttr* __restrict__ tri_attrs;
     const BvhNode* __restrict__ blas_nodes;
     const BvhNode* __restrict__ tlas_nodes;
+    const float4* __restrict__ obj_lo;   // padded world box of every object (what the TLAS is built from)
+    const float4* __restrict__ obj_hi;
     const DMaterial* __restrict__ materials;
     const DTexture* __restrict__ textures;
     const float* __restrict__ texture_data;
     uint32_t n_objects;
     uint32_t n_texture_data;
     uint32_t tlas_root;   // node index, leaf reference, or PT_NONE when there are no objects
+    uint32_t cull_boxes;  // 0: every object is a candidate for every ray (exhaustive loop); 1: cull with the world boxes
+    uint32_t _pad0;
     uint32_t tie_lowest;  // 0: equal distances go to the later (object, triangle) as in the reference; 1: to the earlier
+    uint32_t _pad1;
 };
 
 // Per-frame constants.
@@ -105,6 +110,9 @@ struct FrameParams {
     uint32_t part_index, part_count;
     uint32_t tiles_x, tiles_y;
     uint32_t n_local_tiles;
+    uint32_t chunk;   // pixel numbers a wave takes from the work counter at a time (multiple of 64)
+    uint32_t tile_stride;   // tile visiting order: k-th tile visited = (k * tile_stride) % n_local_tiles, gcd(tile_stride, n_local_tiles) == 1
+    uint32_t refill_min;  // a wave hands out new pixels only when at least this many of its lanes are idle (1..64)
 };
 
 // Work counters accumulated by the trace kernels (one atomic per wave and counter).
@@ -115,5 +123,7 @@ struct DCounters {
     unsigned long long tri_tests;
     unsigned long long shades;
     unsigned long long hits;
-    unsigned long long _pad[2];
+    unsigned int next_pixel;   // work queue head of the frame kernel: next unassigned pixel of this launch
+    unsigned int _pad0;
+    unsigned long long _pad[1];
 };

@@ -14,6 +14,11 @@
 
 #include "pt_scene.h"
 
+// Minimum waves per SIMD the render kernel is compiled for (caps its VGPR allocation).
+#ifndef PT_RENDER_MIN_WAVES
+#define PT_RENDER_MIN_WAVES 4
+#endif
+
 struct Best {
     float t;
     uint32_t obj;
@@ -28,7 +33,7 @@ struct HitInfo {
 };
 
 struct LaneCounters {
-    uint32_t rays, xforms, box_tests, tri_tests, shades, hits;
+    uint32_t xforms, box_tests, tri_tests, shades, hits;
 };
 
 // Per-lane traversal stack in LDS: entry [level][lane], so a wave's push/pop touches 64 consecutive banks.
@@ -49,8 +54,9 @@ PT_DEV bool candidate_wins(float t, uint32_t obj, uint32_t tri, const Best& b, u
 }
 
 // reference src/query.wgsl:95-121, with edges and normal precomputed at upload by the same operations.
+// Returns true when `best` was replaced.
 template <bool STATS>
-PT_DEV void tri_test(const float4 q0, const float4 q1, const float4 q2, v3 o, v3 d, uint32_t obj, uint32_t tri,
+PT_DEV bool tri_test(const float4 q0, const float4 q1, const float4 q2, v3 o, v3 d, uint32_t obj, uint32_t tri,
                      uint32_t tie_lowest, Best& best, LaneCounters& cnt) {
     if (STATS) cnt.tri_tests++;
     v3 a = V3(q0.x, q0.y, q0.z);
@@ -60,25 +66,31 @@ PT_DEV void tri_test(const float4 q0, const float4 q1, const float4 q2, v3 o, v3
     v3 ao = sub3(o, a);
     v3 dao = cross3(ao, d);
     float det = -dot3(d, n);
-    if (det < PT_EPSILON) return;
+    if (det < PT_EPSILON) return false;
+    float un = dot3(e_ac, dao);
+    float vn = -dot3(e_ab, dao);
+    // Early out without the division: for det in [EPSILON, 2^60) the reciprocal is a positive normal number above
+    // 2^-60, so a numerator below -2^-60 gives a product below -2^-120, which cannot round to zero: u (or v) < 0
+    // and the reference rejects. Anything outside these ranges takes the exact path below.
+    if ((un < -0x1p-60f || vn < -0x1p-60f) && det < 0x1p60f) return false;
     float inv_det = pt_div(1.0f, det);
     float t = dot3(ao, n) * inv_det;
-    float u = dot3(e_ac, dao) * inv_det;
-    float v = (-dot3(e_ab, dao)) * inv_det;
+    float u = un * inv_det;
+    float v = vn * inv_det;
     float w = 1.0f - u - v;
-    if (t < PT_T_MIN || u < 0.0f || v < 0.0f || w < 0.0f) return;
-    if (candidate_wins(t, obj, tri, best, tie_lowest)) {
-        best.t = t;
-        best.obj = obj;
-        best.tri = tri;
-        best.u = u;
-        best.v = v;
-    }
+    if (t < PT_T_MIN || u < 0.0f || v < 0.0f || w < 0.0f) return false;
+    if (!candidate_wins(t, obj, tri, best, tie_lowest)) return false;
+    best.t = t;
+    best.obj = obj;
+    best.tri = tri;
+    best.u = u;
+    best.v = v;
+    return true;
 }
 
-// reference src/query.wgsl:127-147; also returns 1/dir for reuse by the BLAS walk.
-PT_DEV float hit_box_exact(const float* bmin, const float* bmax, v3 pos, v3 dir, v3& inv) {
-    inv = V3(pt_div(1.0f, dir.x), pt_div(1.0f, dir.y), pt_div(1.0f, dir.z));
+// reference src/query.wgsl:127-147
+PT_DEV float hit_box_exact(const float* bmin, const float* bmax, v3 pos, v3 dir) {
+    v3 inv = V3(pt_div(1.0f, dir.x), pt_div(1.0f, dir.y), pt_div(1.0f, dir.z));
     float tminx = (bmin[0] - pos.x) * inv.x, tminy = (bmin[1] - pos.y) * inv.y, tminz = (bmin[2] - pos.z) * inv.z;
     float tmaxx = (bmax[0] - pos.x) * inv.x, tmaxy = (bmax[1] - pos.y) * inv.y, tmaxz = (bmax[2] - pos.z) * inv.z;
     float t1x = pt_min(tminx, tmaxx), t1y = pt_min(tminy, tmaxy), t1z = pt_min(tminz, tmaxz);
@@ -90,18 +102,18 @@ PT_DEV float hit_box_exact(const float* bmin, const float* bmax, v3 pos, v3 dir,
     return 0.0f;
 }
 
-// Conservative ray/box test used only for culling. The box is grown by `pad` on every side
-// (folded into ka/kb), reciprocals are clamped to +-2^100 so that axis-parallel rays stay finite,
-// NaNs drop out of min/max (= "no constraint"), and the interval is clipped to [0, tmax].
+// Conservative ray/box test used only for culling. The box is grown by `pad` on every side (folded into ka/kb),
+// the reciprocals come from v_rcp_f32 (1 ulp, far inside the pad) and are clamped to +-2^100 so that axis-parallel
+// rays stay finite, NaNs drop out of min/max (= "no constraint"), and the interval is clipped to [0, tmax].
 struct SlabRay {
-    v3 inv;     // clamped 1/dir
+    v3 inv;     // clamped ~1/dir
     v3 ka, kb;  // -(o+pad)*inv, -(o-pad)*inv
 };
-PT_DEV SlabRay make_slab_ray(v3 o, v3 inv_exact, float pad) {
+PT_DEV SlabRay make_slab_ray(v3 o, v3 d, float pad) {
     SlabRay s;
     const float big = 0x1p100f;
-    s.inv = V3(pt_min(pt_max(inv_exact.x, -big), big), pt_min(pt_max(inv_exact.y, -big), big),
-               pt_min(pt_max(inv_exact.z, -big), big));
+    s.inv = V3(pt_min(pt_max(__builtin_amdgcn_rcpf(d.x), -big), big), pt_min(pt_max(__builtin_amdgcn_rcpf(d.y), -big), big),
+               pt_min(pt_max(__builtin_amdgcn_rcpf(d.z), -big), big));
     s.ka = V3(-(o.x + pad) * s.inv.x, -(o.y + pad) * s.inv.y, -(o.z + pad) * s.inv.z);
     s.kb = V3(-(o.x - pad) * s.inv.x, -(o.y - pad) * s.inv.y, -(o.z - pad) * s.inv.z);
     return s;
@@ -116,114 +128,137 @@ PT_DEV bool slab_test(const SlabRay& s, float4 lo, float4 hi, float tmax, float&
     return tn <= tf;
 }
 
-// Walk one mesh's BLAS in the object's local space. `sp0` is the first free stack level.
-template <bool STATS>
-PT_DEV void blas_walk(const SceneView& sc, uint32_t root, uint32_t tri_first, float mesh_max_abs, uint32_t obj, v3 lo,
-                      v3 ld, v3 inv_exact, Best& best, LdsStack stk, int sp0, LaneCounters& cnt) {
-    float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) +
-                            mesh_max_abs);
-    SlabRay sr = make_slab_ray(lo, inv_exact, pad);
+// Per-lane stack walk of a binary BVH in "while-while" form: every lane first descends through internal nodes
+// until it holds a leaf (or runs out of work), then the lanes that hold a leaf process it together. This keeps the
+// expensive leaf code (object or triangle test) running with as many lanes as possible.
+// `tmax` is read through the reference every time, so leaves that shorten the ray tighten the culling at once.
+#define PT_WALK_DONE 0x7FFFFFFFu
+template <bool STATS, class LeafFn>
+PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t root, const SlabRay& sr, const float& tmax, LdsStack stk,
+                     int sp0, bool active, LaneCounters& cnt, LeafFn leaf) {
+    uint32_t node = active ? root : PT_WALK_DONE;
     int sp = sp0;
-    uint32_t node = root;
-    while (true) {
-        if (!(node & PT_LEAF_BIT)) {
-            const BvhNode* N = &sc.blas_nodes[node];
+    while (__any(node != PT_WALK_DONE)) {
+        while (node != PT_WALK_DONE && !(node & PT_LEAF_BIT)) {
+            const BvhNode* N = &nodes[node];
             float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
             if (STATS) cnt.box_tests += 2;
             float tl, tr;
-            bool hit_l = slab_test(sr, ll, hl, best.t, tl);
-            bool hit_r = slab_test(sr, lr, hr, best.t, tr);
+            bool hit_l = slab_test(sr, ll, hl, tmax, tl);
+            bool hit_r = slab_test(sr, lr, hr, tmax, tr);
             uint32_t cl = __float_as_uint(ll.w), cr = __float_as_uint(lr.w);
             if (hit_l && hit_r) {
                 bool left_first = tl <= tr;
                 stk.put(sp++, left_first ? cr : cl);
                 node = left_first ? cl : cr;
-                continue;
+            } else if (hit_l) {
+                node = cl;
+            } else if (hit_r) {
+                node = cr;
+            } else {
+                node = (sp > sp0) ? stk.get(--sp) : PT_WALK_DONE;
             }
-            if (hit_l) { node = cl; continue; }
-            if (hit_r) { node = cr; continue; }
-        } else {
-            uint32_t tri = node & ~PT_LEAF_BIT;
-            const DTri* T = &sc.tris[tri_first + tri];
-            tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, best, cnt);
         }
-        if (sp == sp0) break;
-        node = stk.get(--sp);
+        if (node != PT_WALK_DONE) {
+            leaf(node & ~PT_LEAF_BIT, sp);
+            node = (sp > sp0) ? stk.get(--sp) : PT_WALK_DONE;
+        }
     }
 }
 
-// hit_mesh for one object (reference src/query.wgsl:66-125): transform, exact gate, triangles.
-// UNIFORM = the object (and therefore the mesh) is the same in every lane of the wave.
+// hit_mesh for one object (reference src/query.wgsl:66-125). Each lane brings its own object; lanes whose objects
+// share a mesh are processed together so that the mesh and triangle records come through the scalar cache.
+// The reference gates the whole mesh on hit_box() BEFORE looking at triangles; the gate only ever rejects, so it
+// is evaluated afterwards and only for objects that produced a winning candidate (the exact arithmetic with its
+// three divisions is then needed once per accepted object instead of once per visited object).
 template <bool STATS>
-PT_DEV void object_test(const SceneView& sc, const DObject* ob, uint32_t obj, v3 ro, v3 rd, Best& best, LdsStack stk,
-                        int sp0, LaneCounters& cnt) {
-    Affine w2l = ob->w2l;
-    uint32_t mesh_id = ob->mesh;
-    v3 lo = xform_point(w2l, ro);
-    v3 ld = xform_dir(w2l, rd);
-    const DMesh* me = &sc.meshes[mesh_id];
+PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& best, LdsStack stk, int sp0,
+                        LaneCounters& cnt) {
+    const DObject* ob = &sc.objects[obj];
+    const Affine w2l = ob->w2l;
+    const uint32_t mesh_id = ob->mesh;
+    const v3 lo = xform_point(w2l, ro);   // reference :73
+    const v3 ld = xform_dir(w2l, rd);     // reference :74
     if (STATS) cnt.xforms++;
-    v3 inv;
-    float t_aabb = hit_box_exact(me->bmin, me->bmax, lo, ld, inv);
-    if (t_aabb < PT_T_MIN) return;
-    uint32_t root = me->blas_root;
-    uint32_t tri_first = me->tri_first;
-    if (root == PT_NONE) {
-        uint32_t n = me->tri_count;
-        for (uint32_t i = 0; i < n; ++i) {
-            const DTri* T = &sc.tris[tri_first + i];
-            tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, best, cnt);
+    Best cand = best;
+    bool changed = false;
+    bool pending = true;
+    while (__any(pending)) {
+        if (pending) {
+            const uint32_t m = __builtin_amdgcn_readfirstlane(mesh_id);
+            if (mesh_id == m) {
+                pending = false;
+                const DMesh* me = &sc.meshes[m];
+                const uint32_t root = me->blas_root, tri_first = me->tri_first;
+                if (root == PT_NONE) {
+                    const uint32_t n = me->tri_count;
+                    for (uint32_t i = 0; i < n; ++i) {
+                        const DTri* T = &sc.tris[tri_first + i];
+                        changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
+                    }
+                } else {
+                    const float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) + me->max_abs);
+                    const SlabRay sr = make_slab_ray(lo, ld, pad);
+                    bvh_walk<STATS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+                        const DTri* T = &sc.tris[tri_first + tri];
+                        changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
+                    });
+                }
+                if (changed) {
+                    const float t_aabb = hit_box_exact(me->bmin, me->bmax, lo, ld);   // reference :77-80
+                    if (!(t_aabb < PT_T_MIN)) best = cand;
+                }
+            }
         }
-    } else {
-        blas_walk<STATS>(sc, root, tri_first, me->max_abs, obj, lo, ld, inv, best, stk, sp0, cnt);
     }
 }
 
-// hit_all, objects visited in index order by the whole wave together (scalar loads of the
-// object, mesh and triangle records). For scenes with a handful of objects.
+PT_DEV SlabRay world_slab_ray(v3 ro, v3 rd) {
+    const float pad = 0x1p-16f * pt_max(pt_max(__builtin_fabsf(ro.x), __builtin_fabsf(ro.y)), __builtin_fabsf(ro.z));
+    return make_slab_ray(ro, rd, pad);
+}
+
+// hit_all without a TLAS: the wave tests the padded world boxes of 32 objects at a time together (scalar loads),
+// each lane collects its own candidates in a bit mask and then works through them.
+// An object whose world box the ray misses cannot contain an accepted triangle, so skipping it changes nothing.
+// With sc.cull_boxes == 0 (PT_ACCEL_BRUTE) every object is a candidate: the reference's exhaustive loop.
 template <bool STATS>
-PT_DEV void closest_hit_uniform(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk,
-                                LaneCounters& cnt) {
-    uint32_t n = sc.n_objects;
-    for (uint32_t o = 0; o < n; ++o) {
-        if (active) object_test<STATS>(sc, &sc.objects[o], o, ro, rd, best, stk, 0, cnt);
+PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
+    const SlabRay sr = world_slab_ray(ro, rd);
+    const uint32_t n = sc.n_objects;
+    const bool cull = sc.cull_boxes != 0;
+    for (uint32_t base = 0; base < n; base += 32) {
+        const uint32_t m = (n - base < 32u) ? n - base : 32u;
+        uint32_t mask = 0;
+        if (cull) {
+            for (uint32_t k = 0; k < m; ++k) {
+                const float4 blo = sc.obj_lo[base + k], bhi = sc.obj_hi[base + k];
+                float tn;
+                if (STATS) cnt.box_tests++;
+                if (slab_test(sr, blo, bhi, best.t, tn)) mask |= 1u << k;
+            }
+        } else {
+            mask = (m == 32u) ? 0xFFFFFFFFu : ((1u << m) - 1u);
+        }
+        if (!active) mask = 0;
+        while (__any(mask != 0)) {
+            if (mask != 0) {
+                const uint32_t o = base + (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1;
+                float tn;
+                if (!cull || slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn)) object_test<STATS>(sc, o, ro, rd, best, stk, 0, cnt);
+            }
+        }
     }
 }
 
 // hit_all through the TLAS: each lane walks the object tree on its own.
 template <bool STATS>
-PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk,
-                             LaneCounters& cnt) {
-    if (!active || sc.tlas_root == PT_NONE) return;
-    v3 inv_w = V3(pt_div(1.0f, rd.x), pt_div(1.0f, rd.y), pt_div(1.0f, rd.z));
-    float pad = 0x1p-16f * pt_max(pt_max(__builtin_fabsf(ro.x), __builtin_fabsf(ro.y)), __builtin_fabsf(ro.z));
-    SlabRay sr = make_slab_ray(ro, inv_w, pad);
-    int sp = 0;
-    uint32_t node = sc.tlas_root;
-    while (true) {
-        if (!(node & PT_LEAF_BIT)) {
-            const BvhNode* N = &sc.tlas_nodes[node];
-            float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
-            if (STATS) cnt.box_tests += 2;
-            float tl, tr;
-            bool hit_l = slab_test(sr, ll, hl, best.t, tl);
-            bool hit_r = slab_test(sr, lr, hr, best.t, tr);
-            uint32_t cl = __float_as_uint(ll.w), cr = __float_as_uint(lr.w);
-            if (hit_l && hit_r) {
-                bool left_first = tl <= tr;
-                stk.put(sp++, left_first ? cr : cl);
-                node = left_first ? cl : cr;
-                continue;
-            }
-            if (hit_l) { node = cl; continue; }
-            if (hit_r) { node = cr; continue; }
-        } else {
-            uint32_t obj = node & ~PT_LEAF_BIT;
-            object_test<STATS>(sc, &sc.objects[obj], obj, ro, rd, best, stk, sp, cnt);
-        }
-        if (sp == 0) break;
-        node = stk.get(--sp);
-    }
+PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
+    if (sc.tlas_root == PT_NONE) return;
+    const SlabRay sr = world_slab_ray(ro, rd);
+    bvh_walk<STATS>(sc.tlas_nodes, sc.tlas_root, sr, best.t, stk, 0, active, cnt,
+                    [&](uint32_t obj, int sp) { object_test<STATS>(sc, obj, ro, rd, best, stk, sp, cnt); });
 }
 
 template <bool TLAS, bool STATS>
@@ -234,7 +269,7 @@ PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& be
     best.u = 0.0f;
     best.v = 0.0f;
     if (TLAS) closest_hit_tlas<STATS>(sc, ro, rd, active, best, stk, cnt);
-    else closest_hit_uniform<STATS>(sc, ro, rd, active, best, stk, cnt);
+    else closest_hit_list<STATS>(sc, ro, rd, active, best, stk, cnt);
 }
 
 // The hit_record of the winner (reference src/query.wgsl:113-120), evaluated once per ray.
@@ -343,151 +378,247 @@ PT_DEV uint32_t wave_sum_u32(uint32_t v) {
 }
 
 // ---- the frame kernel ---------------------------------------------------------------
-// One lane per pixel, one wave per 8x8 pixel tile, four tiles per workgroup. The reference's
-// `for sample { for bounce {...} }` nest is flattened into one loop in which every lane always
-// has a ray of its own to trace: a lane whose path ends starts its pixel's next sample in the
-// same iteration, so lanes idle only once their pixel is completely finished. The order of RNG
-// draws and of every floating-point accumulation per pixel is the reference's.
-// The primary ray is identical for every sample of a pixel (src/raytrace.wgsl:223 restarts from
-// the same origin/direction, no jitter), so its closest hit is computed once and reused.
+// Persistent waves with per-lane refill. A lane owns one pixel at a time and keeps the reference's per-pixel
+// order of RNG draws and of every f32 accumulation (`for sample { for bounce {...} }`, src/raytrace.wgsl:221-273);
+// across pixels nothing is shared. Every round of the loop below
+//   A. hands a new pixel to each idle lane (one wave-aggregated atomic on a global pixel counter; pixels are
+//      numbered tile by tile so that a wave's lanes stay on neighbouring pixels),
+//   B. traces one ray for every lane that has one (primary or secondary - same code),
+//   C. shades: a lane whose path ends moves on to the pixel's next sample and shades the cached primary hit
+//      right away, until it holds a new ray or the pixel is complete.
+// So the closest-hit code always runs with (nearly) all lanes, however uneven the path lengths are.
+// The primary ray is identical for every sample of a pixel (src/raytrace.wgsl:223 restarts from the same
+// origin/direction, no jitter), so its closest hit is traced once per pixel and its hit record kept in LDS.
+#define PT_ST_IDLE 0u
+#define PT_ST_TRACE 1u
+#define PT_ST_SHADE 2u
+#define PT_LANE_SLOTS 12  // per-lane LDS words: cached primary hit record (9) + primary direction (3)
+
 template <bool TLAS, bool STATS>
-__global__ __launch_bounds__(256) void k_render(SceneView sc, FrameParams fp, uint32_t stack_depth, float4* __restrict__ out,
-                                                uint32_t* __restrict__ aux_obj, uint32_t* __restrict__ aux_flat,
-                                                float* __restrict__ aux_t, uint32_t* __restrict__ aux_rays,
-                                                DCounters* __restrict__ counters) {
-    extern __shared__ uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
+__global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(SceneView sc, FrameParams fp, uint32_t stack_depth,
+                                                                     float4* __restrict__ out, uint32_t* __restrict__ aux_obj,
+                                                                     uint32_t* __restrict__ aux_flat, float* __restrict__ aux_t,
+                                                                     uint32_t* __restrict__ aux_rays, DCounters* __restrict__ counters) {
+    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes] stacks, then [4 waves][PT_LANE_SLOTS][64 lanes]
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t local_tile = blockIdx.x * 4 + wave;
-    if (local_tile >= fp.n_local_tiles) return;  // wave-uniform
     LdsStack stk;
-    stk.base = &s_stack[wave * stack_depth * 64 + lane];
+    stk.base = &s_mem[wave * stack_depth * 64 + lane];
+    float* slot = reinterpret_cast<float*>(&s_mem[4 * stack_depth * 64 + wave * PT_LANE_SLOTS * 64 + lane]);  // slot[k*64]
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    const uint32_t tile = local_tile * fp.part_count + fp.part_index;
-    const uint32_t ty = tile / fp.tiles_x, tx = tile - ty * fp.tiles_x;
-    const uint32_t px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-    const bool valid = px < fp.width && py < fp.height;
-
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
-
-    // fullscreen triangle at the pixel centre; src/raytrace.wgsl:210-217
     const float W = (float)fp.width, H = (float)fp.height;
-    const float uvx = pt_div((float)px + 0.5f, W), uvy = pt_div((float)py + 0.5f, H);
     const float tp1 = fp.time + 1.0f;
-    const float sx = (uvx * W) * tp1, sy = (uvy * H) * tp1;
-    Rng rng;
-    rng.x = pt_f2u(sx);
-    rng.y = pt_f2u(sy);
-    rng.z = rng.x ^ rng.y;
-    const float dx = uvx * 2.0f - 1.0f;
-    const float dy = (uvy * 2.0f - 1.0f) * -1.0f;
     const v3 origin = V3(fp.wfv[12], fp.wfv[13], fp.wfv[14]);
-    v3 temp = V3(pt_fma(fp.vfc[4], dy, fp.vfc[0] * dx) + fp.vfc[8] + fp.vfc[12],
-                 pt_fma(fp.vfc[5], dy, fp.vfc[1] * dx) + fp.vfc[9] + fp.vfc[13],
-                 pt_fma(fp.vfc[6], dy, fp.vfc[2] * dx) + fp.vfc[10] + fp.vfc[14]);
-    temp = normalize3(temp);
-    const v3 dir0 = V3(pt_fma(fp.wfv[8], temp.z, pt_fma(fp.wfv[4], temp.y, fp.wfv[0] * temp.x)),
-                       pt_fma(fp.wfv[9], temp.z, pt_fma(fp.wfv[5], temp.y, fp.wfv[1] * temp.x)),
-                       pt_fma(fp.wfv[10], temp.z, pt_fma(fp.wfv[6], temp.y, fp.wfv[2] * temp.x)));
-
     const uint32_t bounces = fp.bounces, samples = fp.samples;
+    const float ns = (float)samples;
     const v3 sky = V3(fp.sky[0], fp.sky[1], fp.sky[2]);
     const bool any_rays = bounces > 0 && samples > 0;
+    const uint32_t total = fp.n_local_tiles * 64u;
 
-    // primary closest hit, once per pixel
-    Best pb;
-    pb.t = PT_T_MAX; pb.obj = PT_NONE; pb.tri = PT_NONE; pb.u = 0.0f; pb.v = 0.0f;
-    HitInfo hp;
-    hp.obj = PT_NONE; hp.p = V3(0, 0, 0); hp.n = V3(0, 0, 0); hp.u = 0.0f; hp.v = 0.0f;
-    if (any_rays) {
-        closest_hit<TLAS, STATS>(sc, origin, dir0, valid, pb, stk, cnt);
-        if (valid) {
-            cnt.rays = 1;
-            if (STATS && pb.obj != PT_NONE) cnt.hits++;
-            hp = finalize_hit(sc, origin, dir0, pb);
+    LaneCounters cnt = {0, 0, 0, 0, 0};
+    uint32_t wave_rays = 0;  // per lane, summed at the end
+
+    // per-pixel state
+    uint32_t st = PT_ST_IDLE, pix = 0, sample = 0, bounce = 0, nrays = 0;
+    bool primary_pending = false;
+    Rng rng = {0, 0, 0};
+    v3 rpos = origin, rdir = V3(0, 0, 1);
+    v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0), pixel_color = V3(0, 0, 0);
+    HitInfo h;
+    h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
+    bool exhausted = false;                    // wave-uniform: the global pixel counter has run out
+    uint32_t chunk_next = 0, chunk_end = 0;    // wave-uniform: this wave's current chunk of pixel numbers
+
+    for (;;) {
+        // ---- A. refill idle lanes --------------------------------------------------------------------
+        // The wave owns a chunk of consecutive pixel numbers (a few neighbouring tiles) and hands them to its idle
+        // lanes; when the chunk runs out it takes the next one from the global counter. Lanes of one wave therefore
+        // stay on at most two small image regions at any time, which keeps their rays and candidates similar.
+        {
+            bool need = st == PT_ST_IDLE;
+            unsigned long long m = __ballot(need);
+            // refill only once enough lanes are free, so that the newcomers share a tile
+            if ((uint32_t)__popcll(m) < fp.refill_min) m = 0ull;
+            while (m != 0ull && !exhausted) {
+                if (chunk_next == chunk_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&counters->next_pixel, fp.chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total) {
+                        exhausted = true;
+                        break;
+                    }
+                    chunk_next = base;
+                    chunk_end = (total - base < fp.chunk) ? total : base + fp.chunk;
+                }
+                const uint32_t avail = chunk_end - chunk_next;
+                const uint32_t want = (uint32_t)__popcll(m);
+                const uint32_t take = want < avail ? want : avail;
+                const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
+                if (need && rank < take) {
+                    need = false;
+                    const uint32_t idx = chunk_next + rank;
+                    // tiles are visited in a scattered order (multiplication by a constant coprime to the tile count), so
+                    // that cheap and expensive image regions are spread over the whole launch instead of expensive ones
+                    // piling up at its end
+                    const uint32_t local_tile = (uint32_t)(((unsigned long long)(idx >> 6) * fp.tile_stride) % fp.n_local_tiles), within = idx & 63u;
+                    const uint32_t tile = local_tile * fp.part_count + fp.part_index;
+                    const uint32_t ty = tile / fp.tiles_x, tx = tile - ty * fp.tiles_x;
+                    const uint32_t px = tx * 8 + (within & 7u), py = ty * 8 + (within >> 3);
+                    if (px < fp.width && py < fp.height) {
+                        pix = py * fp.width + px;
+                        // fullscreen triangle at the pixel centre; src/raytrace.wgsl:210-217
+                        const float uvx = pt_div((float)px + 0.5f, W), uvy = pt_div((float)py + 0.5f, H);
+                        const float sx = (uvx * W) * tp1, sy = (uvy * H) * tp1;
+                        rng.x = pt_f2u(sx);
+                        rng.y = pt_f2u(sy);
+                        rng.z = rng.x ^ rng.y;
+                        const float dx = uvx * 2.0f - 1.0f;
+                        const float dy = (uvy * 2.0f - 1.0f) * -1.0f;
+                        v3 temp = V3(pt_fma(fp.vfc[4], dy, fp.vfc[0] * dx) + fp.vfc[8] + fp.vfc[12],
+                                     pt_fma(fp.vfc[5], dy, fp.vfc[1] * dx) + fp.vfc[9] + fp.vfc[13],
+                                     pt_fma(fp.vfc[6], dy, fp.vfc[2] * dx) + fp.vfc[10] + fp.vfc[14]);
+                        temp = normalize3(temp);
+                        const v3 dir0 = V3(pt_fma(fp.wfv[8], temp.z, pt_fma(fp.wfv[4], temp.y, fp.wfv[0] * temp.x)),
+                                           pt_fma(fp.wfv[9], temp.z, pt_fma(fp.wfv[5], temp.y, fp.wfv[1] * temp.x)),
+                                           pt_fma(fp.wfv[10], temp.z, pt_fma(fp.wfv[6], temp.y, fp.wfv[2] * temp.x)));
+                        slot[9 * 64] = dir0.x; slot[10 * 64] = dir0.y; slot[11 * 64] = dir0.z;
+                        sample = 0; bounce = 0; nrays = 0;
+                        pixel_color = V3(0, 0, 0);
+                        ray_color = V3(1, 1, 1);
+                        color = V3(0, 0, 0);
+                        rpos = origin;
+                        rdir = dir0;
+                        if (any_rays) {
+                            st = PT_ST_TRACE;
+                            primary_pending = true;
+                        } else {
+                            // no ray is ever traced: `samples` additions of zero, then the division (0/0 when samples == 0)
+                            out[pix] = make_float4(pt_div(0.0f, ns), pt_div(0.0f, ns), pt_div(0.0f, ns), 1.0f);
+                            aux_obj[pix] = PT_NONE; aux_flat[pix] = PT_NONE; aux_t[pix] = PT_T_MAX; aux_rays[pix] = 0u;
+                            need = true;  // this lane is free again at once
+                        }
+                    } else {
+                        need = true;      // pixel number outside the image (ragged edge tile)
+                    }
+                }
+                chunk_next += take;
+                m = __ballot(need);
+            }
         }
-    }
-    if (valid) {
-        const uint32_t pix = py * fp.width + px;
-        aux_obj[pix] = pb.obj;
-        aux_flat[pix] = (pb.obj != PT_NONE) ? sc.objects[pb.obj].tri_base + pb.tri : PT_NONE;
-        aux_t[pix] = pb.t;
-    }
+        if (!__any(st != PT_ST_IDLE)) {
+            if (exhausted) break;
+            continue;
+        }
 
-    v3 pixel_color = V3(0, 0, 0);
-    uint32_t sample = 0, bounce = 0;
-    v3 rpos = origin, rdir = dir0;
-    v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0);
-    bool active = valid && samples > 0;
-
-    while (__any(active)) {
-        // 1. closest hit for lanes that are past their first segment
-        HitInfo h = hp;
-        if (bounces > 0) {
-            bool need = active && bounce > 0;
-            if (__any(need)) {
-                Best b;
-                closest_hit<TLAS, STATS>(sc, rpos, rdir, need, b, stk, cnt);
-                if (need) {
-                    cnt.rays++;
-                    if (STATS && b.obj != PT_NONE) cnt.hits++;
-                    h = finalize_hit(sc, rpos, rdir, b);
+        // ---- B. trace --------------------------------------------------------------------------------
+        {
+            const bool tracing = st == PT_ST_TRACE;
+            Best b;
+            closest_hit<TLAS, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
+            if (tracing) {
+                nrays++;
+                wave_rays++;
+                if (STATS && b.obj != PT_NONE) cnt.hits++;
+                h = finalize_hit(sc, rpos, rdir, b);
+                st = PT_ST_SHADE;
+                if (primary_pending) {
+                    primary_pending = false;
+                    slot[0] = __uint_as_float(h.obj);
+                    slot[1 * 64] = h.p.x; slot[2 * 64] = h.p.y; slot[3 * 64] = h.p.z;
+                    slot[4 * 64] = h.n.x; slot[5 * 64] = h.n.y; slot[6 * 64] = h.n.z;
+                    slot[7 * 64] = h.u; slot[8 * 64] = h.v;
+                    aux_obj[pix] = b.obj;
+                    aux_flat[pix] = (b.obj != PT_NONE) ? sc.objects[b.obj].tri_base + b.tri : PT_NONE;
+                    aux_t[pix] = b.t;
+                    // Pixels whose primary hit ends every path at once - a miss, or a surface whose albedo is black
+                    // (the emissive lights): no scatter, no RNG draw, every sample adds the same colour.
+                    bool terminal = false;
+                    v3 c = sky;
+                    if (h.obj != PT_NONE) {
+                        const DMaterial m = sc.materials[sc.objects[h.obj].mat];
+                        const v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+                        if (dot3(alb, alb) < PT_EPSILON) {
+                            terminal = true;
+                            c = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
+                            if (m.emissive_texture != PT_NONE) c = sample_texture(sc, m.emissive_texture, h.u, h.v);
+                        }
+                    } else {
+                        terminal = true;
+                    }
+                    if (terminal) {
+                        c = V3(pt_fma(1.0f, c.x, 0.0f), pt_fma(1.0f, c.y, 0.0f), pt_fma(1.0f, c.z, 0.0f));
+                        for (uint32_t k = 0; k < samples; ++k) pixel_color = add3(pixel_color, c);
+                        out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
+                        aux_rays[pix] = samples;  // the reference traces the primary ray once per sample
+                        st = PT_ST_IDLE;
+                    }
                 }
             }
         }
-        // 2. shade (src/raytrace.wgsl:229-270) and advance the (sample, bounce) state
-        if (active) {
-            bool end_path = false;
-            if (bounces == 0) {
-                end_path = true;
-            } else if (h.obj != PT_NONE) {
-                const DMaterial m = sc.materials[sc.objects[h.obj].mat];
-                v3 emissive = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
-                if (m.emissive_texture != PT_NONE) emissive = sample_texture(sc, m.emissive_texture, h.u, h.v);
-                color = V3(pt_fma(ray_color.x, emissive.x, color.x), pt_fma(ray_color.y, emissive.y, color.y),
-                           pt_fma(ray_color.z, emissive.z, color.z));
-                v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
-                if (dot3(alb, alb) < PT_EPSILON) {
-                    end_path = true;
+
+        // ---- C. shade (src/raytrace.wgsl:229-270) and advance (sample, bounce) -----------------------------
+        bool pending = st == PT_ST_SHADE;
+        while (__any(pending)) {
+            if (pending) {
+                bool end_path = false;
+                if (h.obj != PT_NONE) {
+                    const DMaterial m = sc.materials[sc.objects[h.obj].mat];
+                    v3 emissive = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
+                    if (m.emissive_texture != PT_NONE) emissive = sample_texture(sc, m.emissive_texture, h.u, h.v);
+                    color = V3(pt_fma(ray_color.x, emissive.x, color.x), pt_fma(ray_color.y, emissive.y, color.y),
+                               pt_fma(ray_color.z, emissive.z, color.z));
+                    const v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+                    if (dot3(alb, alb) < PT_EPSILON) {
+                        end_path = true;
+                    } else {
+                        v3 N = h.n;
+                        if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
+                        v3 ndir, bcol;
+                        if (STATS) cnt.shades++;
+                        calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
+                        rdir = ndir;
+                        rpos = madd3(h.p, rdir, 0.001f);
+                        ray_color = mul3(ray_color, bcol);
+                        const float p = pt_max(ray_color.x, pt_max(ray_color.y, ray_color.z));
+                        bounce++;
+                        if (p < PT_EPSILON || bounce >= bounces) end_path = true;
+                    }
                 } else {
-                    v3 N = h.n;
-                    if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
-                    v3 ndir, bcol;
-                    if (STATS) cnt.shades++;
-                    calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
-                    rdir = ndir;
-                    rpos = madd3(h.p, rdir, 0.001f);
-                    ray_color = mul3(ray_color, bcol);
-                    float p = pt_max(ray_color.x, pt_max(ray_color.y, ray_color.z));
-                    bounce++;
-                    if (p < PT_EPSILON || bounce >= bounces) end_path = true;
+                    color = V3(pt_fma(ray_color.x, sky.x, color.x), pt_fma(ray_color.y, sky.y, color.y),
+                               pt_fma(ray_color.z, sky.z, color.z));
+                    end_path = true;
                 }
-            } else {
-                color = V3(pt_fma(ray_color.x, sky.x, color.x), pt_fma(ray_color.y, sky.y, color.y),
-                           pt_fma(ray_color.z, sky.z, color.z));
-                end_path = true;
-            }
-            if (end_path) {
-                pixel_color = add3(pixel_color, color);
-                sample++;
-                bounce = 0;
-                rpos = origin;
-                rdir = dir0;
-                ray_color = V3(1, 1, 1);
-                color = V3(0, 0, 0);
-                if (sample >= samples) active = false;
+                if (end_path) {
+                    pixel_color = add3(pixel_color, color);
+                    sample++;
+                    if (sample >= samples) {
+                        out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
+                        // queries the reference would have run: it re-traces the primary ray for every sample
+                        aux_rays[pix] = nrays + samples - 1u;
+                        st = PT_ST_IDLE;
+                        pending = false;
+                    } else {
+                        bounce = 0;
+                        rpos = origin;
+                        rdir = V3(slot[9 * 64], slot[10 * 64], slot[11 * 64]);
+                        ray_color = V3(1, 1, 1);
+                        color = V3(0, 0, 0);
+                        h.obj = __float_as_uint(slot[0]);
+                        h.p = V3(slot[1 * 64], slot[2 * 64], slot[3 * 64]);
+                        h.n = V3(slot[4 * 64], slot[5 * 64], slot[6 * 64]);
+                        h.u = slot[7 * 64];
+                        h.v = slot[8 * 64];
+                    }
+                } else {
+                    st = PT_ST_TRACE;
+                    pending = false;
+                }
             }
         }
     }
 
-    if (valid) {
-        const uint32_t pix = py * fp.width + px;
-        const float ns = (float)samples;
-        out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
-        // queries the reference would have run: it re-traces the primary ray for every sample
-        aux_rays[pix] = cnt.rays + (any_rays ? samples - 1u : 0u);
-    }
-
-    uint32_t r = wave_sum_u32(valid ? cnt.rays : 0u);
+    uint32_t r = wave_sum_u32(wave_rays);
     if (lane == 0) atomicAdd(&counters->rays, (unsigned long long)r);
     if (STATS) {
         uint32_t a = wave_sum_u32(cnt.xforms), b = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
@@ -527,7 +658,7 @@ __global__ __launch_bounds__(256) void k_query(SceneView sc, uint32_t stack_dept
         ro = V3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
         rd = V3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
     }
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0};
     Best b;
     closest_hit<TLAS, false>(sc, ro, rd, valid, b, stk, cnt);
     if (!valid) return;
