@@ -264,6 +264,9 @@ typedef struct PtStats {
     double build_ms;        /* device time of the last TLAS build                */
     uint32_t trace_launches;/* kernel launches that trace_ms covers              */
     uint32_t accel_used;    /* bit 0: TLAS traversal, bit 1: BLAS traversal      */
+    /* detail only: shader cycles summed over waves spent handing out pixels, in
+     * closest hit, and in shading; rounds of the wave loop; lanes tracing per round */
+    uint64_t cycles_refill, cycles_trace, cycles_shade, wave_rounds, lane_rounds;
 } PtStats;
 
 /* detail != 0 re-runs nothing; it only selects whether the next renders also

@@ -32,7 +32,9 @@
  *     M*(v,1) adds M[3][i] last
  *   - a + b*s    = fma(b,s,a) component-wise; mix(a,b,t) = fma(b,t, a*(1-t))
  *   - reflect(I,N) = fma(-(2*dot(N,I)), N, I)
- *   - normalize(v) = v / sqrt(dot(v,v)) with correctly rounded sqrt and divide
+ *   - normalize(v) = v * (1 / sqrt(dot(v,v))) with correctly rounded sqrt and divide
+ *     (one reciprocal and three multiplies, the form GPU compilers emit; within WGSL's
+ *     accuracy bound for normalize)
  *   - min/max = fminf/fmaxf; u32(f) truncates and saturates (NaN -> 0)
  *   - sin/cos  : Cody-Waite reduction by pi/2 + degree-7/8 polynomials (below)
  *   - pow(x,5) = ((x*x)*(x*x))*x
@@ -98,8 +100,8 @@ static inline v3 madd3(v3 a, v3 b, float s) { /* a + b*s */
     return V3(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z));
 }
 static inline v3 normalize3(v3 a) {
-    float l = sqrtf(dot3(a, a));
-    return V3(a.x / l, a.y / l, a.z / l);
+    float r = 1.0f / sqrtf(dot3(a, a));
+    return V3(a.x * r, a.y * r, a.z * r);
 }
 static inline v3 xform_dir(const float* m, v3 v) {
     return V3(fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)),

@@ -534,6 +534,11 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.tri_tests = c.tri_tests;
     ctx->stats.shades = c.shades;
     ctx->stats.hits = c.hits;
+    ctx->stats.cycles_refill = c.cyc_refill;
+    ctx->stats.cycles_trace = c.cyc_trace;
+    ctx->stats.cycles_shade = c.cyc_shade;
+    ctx->stats.wave_rounds = c.rounds;
+    ctx->stats.lane_rounds = c.lane_rounds;
     ctx->stats.paths = ctx->last_paths;
     ctx->stats.rays_reference = c.rays + ctx->last_primary;
     ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u);
@@ -603,7 +608,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     const bool st = ctx->stats_detail;
     // persistent waves: as many workgroups as fit on the chip at once (or fewer for small frames); they pull pixels
     // from a counter until the frame is done
-    using RenderFn = void (*)(SceneView, FrameParams, uint32_t, float4*, uint32_t*, uint32_t*, float*, uint32_t*, DCounters*);
+    using RenderFn = void (*)(PT_SCENE_PARAMS, FrameParams, uint32_t, float4*, uint32_t*, uint32_t*, float*, uint32_t*, DCounters*);
     RenderFn fn = ctx->use_tlas ? (st ? k_render<true, true> : k_render<true, false>) : (st ? k_render<false, true> : k_render<false, false>);
     int per_cu = 0;
     PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds));
@@ -613,7 +618,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     const uint32_t grid = std::min(div_up(fp.n_local_tiles, 4), resident);
     PT_HIP(ctx, hipEventRecord(ctx->ev0, s));
     if (grid) {
-        fn<<<grid, 256, lds, s>>>(sv, fp, depth, reinterpret_cast<float4*>(out), ctx->d_aux_obj.as<uint32_t>(),
+        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, reinterpret_cast<float4*>(out), ctx->d_aux_obj.as<uint32_t>(),
                                   ctx->d_aux_flat.as<uint32_t>(), ctx->d_aux_t.as<float>(), ctx->d_aux_rays.as<uint32_t>(),
                                   ctx->d_counters.as<DCounters>());
         PT_HIP(ctx, hipGetLastError());
@@ -703,8 +708,8 @@ int pt_query(pt_ctx* ctx, const PtRay* rays_host, uint32_t n_rays, PtHit* hits_h
         SceneView sv = make_view(ctx);
         const uint32_t depth = stack_depth_needed(ctx);
         const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t);
-        if (ctx->use_tlas) k_query<true><<<div_up(n_rays, 256), 256, lds, s>>>(sv, depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
-        else k_query<false><<<div_up(n_rays, 256), 256, lds, s>>>(sv, depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        if (ctx->use_tlas) k_query<true><<<div_up(n_rays, 256), 256, lds, s>>>(PT_SCENE_ARGS(sv), depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        else k_query<false><<<div_up(n_rays, 256), 256, lds, s>>>(PT_SCENE_ARGS(sv), depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
         PT_HIP(ctx, hipGetLastError());
         PT_HIP(ctx, hipMemcpyAsync(hits_host, ctx->d_hits.p, sizeof(PtHit) * (size_t)n_rays, hipMemcpyDeviceToHost, s));
         PT_HIP(ctx, hipStreamSynchronize(s));

@@ -12,7 +12,7 @@
 //   cross(a,b) = ( fma(a.y,b.z,-(a.z*b.y)), fma(a.z,b.x,-(a.x*b.z)), fma(a.x,b.y,-(a.y*b.x)) )
 //   M*(v,0)    : r_i = fma(M[2][i],v.z, fma(M[1][i],v.y, M[0][i]*v.x)); M*(v,1) adds M[3][i] last
 //   a + b*s    = fma(b,s,a);  mix(a,b,t) = fma(b,t, a*(1-t));  reflect(I,N) = fma(-(2*dot(N,I)), N, I)
-//   normalize(v) = v / sqrt(dot(v,v));  pow(x,5) = ((x*x)*(x*x))*x
+//   normalize(v) = v * (1 / sqrt(dot(v,v)));  pow(x,5) = ((x*x)*(x*x))*x
 //   sin/cos: Cody-Waite reduction by pi/2 and fixed polynomials (pt_sincos).
 #pragma once
 
@@ -48,8 +48,8 @@ PT_DEV v3 madd3(v3 a, v3 b, float s) { return V3(pt_fma(b.x, s, a.x), pt_fma(b.y
 PT_DEV float pt_div(float a, float b) { return a / b; }       // correctly rounded (hipcc default)
 PT_DEV float pt_sqrt(float a) { return __builtin_sqrtf(a); }  // correctly rounded (hipcc default)
 PT_DEV v3 normalize3(v3 a) {
-    float l = pt_sqrt(dot3(a, a));
-    return V3(pt_div(a.x, l), pt_div(a.y, l), pt_div(a.z, l));
+    float r = pt_div(1.0f, pt_sqrt(dot3(a, a)));
+    return V3(a.x * r, a.y * r, a.z * r);
 }
 PT_DEV float pt_min(float a, float b) { return __builtin_fminf(a, b); }
 PT_DEV float pt_max(float a, float b) { return __builtin_fmaxf(a, b); }

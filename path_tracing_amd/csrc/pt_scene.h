@@ -99,6 +99,30 @@ struct SceneView {
     uint32_t _pad1;
 };
 
+// The kernels take the scene arrays as separate `const T* __restrict__` parameters (PT_SCENE_PARAMS) and rebuild a
+// SceneView from them: only then does the compiler know that the image stores cannot alias the scene, which lets it
+// fetch wave-uniform records (object boxes, mesh and triangle records in the mesh loop) through the scalar cache.
+struct SceneScalars {
+    uint32_t n_objects, n_texture_data, tlas_root, cull_boxes, tie_lowest;
+};
+#define PT_SCENE_PARAMS                                                                                                \
+    const DObject *__restrict__ p_objects, const DMesh *__restrict__ p_meshes, const DTri *__restrict__ p_tris,         \
+        const DTriAttr *__restrict__ p_attrs, const BvhNode *__restrict__ p_blas, const BvhNode *__restrict__ p_tlas,   \
+        const float4 *__restrict__ p_obj_lo, const float4 *__restrict__ p_obj_hi,                                       \
+        const DMaterial *__restrict__ p_materials, const DTexture *__restrict__ p_textures,                             \
+        const float *__restrict__ p_texdata, SceneScalars ss
+#define PT_SCENE_ARGS(v)                                                                                               \
+    (v).objects, (v).meshes, (v).tris, (v).tri_attrs, (v).blas_nodes, (v).tlas_nodes, (v).obj_lo, (v).obj_hi,           \
+        (v).materials, (v).textures, (v).texture_data,                                                                  \
+        SceneScalars { (v).n_objects, (v).n_texture_data, (v).tlas_root, (v).cull_boxes, (v).tie_lowest }
+#define PT_SCENE_VIEW_FROM_PARAMS()                                                                                    \
+    SceneView sc;                                                                                                       \
+    sc.objects = p_objects; sc.meshes = p_meshes; sc.tris = p_tris; sc.tri_attrs = p_attrs; sc.blas_nodes = p_blas;     \
+    sc.tlas_nodes = p_tlas; sc.obj_lo = p_obj_lo; sc.obj_hi = p_obj_hi; sc.materials = p_materials;                     \
+    sc.textures = p_textures; sc.texture_data = p_texdata; sc.n_objects = ss.n_objects;                                 \
+    sc.n_texture_data = ss.n_texture_data; sc.tlas_root = ss.tlas_root; sc.cull_boxes = ss.cull_boxes;                  \
+    sc._pad0 = 0; sc.tie_lowest = ss.tie_lowest; sc._pad1 = 0;
+
 // Per-frame constants.
 struct FrameParams {
     float wfv[16];   // view.world_from_view, column-major
@@ -126,4 +150,6 @@ struct DCounters {
     unsigned int next_pixel;   // work queue head of the frame kernel: next unassigned pixel of this launch
     unsigned int _pad0;
     unsigned long long _pad[1];
+    // phase clocks of the frame kernel (shader cycles summed over waves), STATS variant only
+    unsigned long long cyc_refill, cyc_trace, cyc_shade, rounds, lane_rounds, _pad2[3];
 };

@@ -186,7 +186,11 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
     while (__any(pending)) {
         if (pending) {
             const uint32_t m = __builtin_amdgcn_readfirstlane(mesh_id);
-            if (mesh_id == m) {
+            // Compare against a laundered copy: with `mesh_id == m` the compiler would substitute the per-lane id for
+            // the uniform one inside the branch and fetch the mesh and triangle records with vector loads again.
+            uint32_t m_cmp = m;
+            asm volatile("" : "+s"(m_cmp));
+            if (mesh_id == m_cmp) {
                 pending = false;
                 const DMesh* me = &sc.meshes[m];
                 const uint32_t root = me->blas_root, tri_first = me->tri_first;
@@ -395,10 +399,11 @@ PT_DEV uint32_t wave_sum_u32(uint32_t v) {
 #define PT_LANE_SLOTS 12  // per-lane LDS words: cached primary hit record (9) + primary direction (3)
 
 template <bool TLAS, bool STATS>
-__global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(SceneView sc, FrameParams fp, uint32_t stack_depth,
+__global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(PT_SCENE_PARAMS, FrameParams fp, uint32_t stack_depth,
                                                                      float4* __restrict__ out, uint32_t* __restrict__ aux_obj,
                                                                      uint32_t* __restrict__ aux_flat, float* __restrict__ aux_t,
                                                                      uint32_t* __restrict__ aux_rays, DCounters* __restrict__ counters) {
+    PT_SCENE_VIEW_FROM_PARAMS()
     extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes] stacks, then [4 waves][PT_LANE_SLOTS][64 lanes]
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;
@@ -429,7 +434,10 @@ __global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(SceneView s
     bool exhausted = false;                    // wave-uniform: the global pixel counter has run out
     uint32_t chunk_next = 0, chunk_end = 0;    // wave-uniform: this wave's current chunk of pixel numbers
 
+    unsigned long long cyc_refill = 0, cyc_trace = 0, cyc_shade = 0, n_rounds = 0, lane_rounds = 0;  // STATS only, wave-uniform
     for (;;) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if (STATS) t0 = __builtin_amdgcn_s_memtime();
         // ---- A. refill idle lanes --------------------------------------------------------------------
         // The wave owns a chunk of consecutive pixel numbers (a few neighbouring tiles) and hands them to its idle
         // lanes; when the chunk runs out it takes the next one from the global counter. Lanes of one wave therefore
@@ -512,6 +520,11 @@ __global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(SceneView s
         }
 
         // ---- B. trace --------------------------------------------------------------------------------
+        if (STATS) {
+            t1 = __builtin_amdgcn_s_memtime();
+            n_rounds++;
+            lane_rounds += (unsigned long long)__popcll(__ballot(st == PT_ST_TRACE));
+        }
         {
             const bool tracing = st == PT_ST_TRACE;
             Best b;
@@ -558,6 +571,7 @@ __global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(SceneView s
         }
 
         // ---- C. shade (src/raytrace.wgsl:229-270) and advance (sample, bounce) -----------------------------
+        if (STATS) t2 = __builtin_amdgcn_s_memtime();
         bool pending = st == PT_ST_SHADE;
         while (__any(pending)) {
             if (pending) {
@@ -616,6 +630,12 @@ __global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(SceneView s
                 }
             }
         }
+        if (STATS) {
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            cyc_refill += t1 - t0;
+            cyc_trace += t2 - t1;
+            cyc_shade += t3 - t2;
+        }
     }
 
     uint32_t r = wave_sum_u32(wave_rays);
@@ -624,6 +644,11 @@ __global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(SceneView s
         uint32_t a = wave_sum_u32(cnt.xforms), b = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
                  d = wave_sum_u32(cnt.shades), e = wave_sum_u32(cnt.hits);
         if (lane == 0) {
+            atomicAdd(&counters->cyc_refill, cyc_refill);
+            atomicAdd(&counters->cyc_trace, cyc_trace);
+            atomicAdd(&counters->cyc_shade, cyc_shade);
+            atomicAdd(&counters->rounds, n_rounds);
+            atomicAdd(&counters->lane_rounds, lane_rounds);
             atomicAdd(&counters->hits, (unsigned long long)e);
             atomicAdd(&counters->xforms, (unsigned long long)a);
             atomicAdd(&counters->box_tests, (unsigned long long)b);
@@ -645,8 +670,9 @@ struct DHit {
 };
 
 template <bool TLAS>
-__global__ __launch_bounds__(256) void k_query(SceneView sc, uint32_t stack_depth, const DRay* __restrict__ rays,
+__global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_depth, const DRay* __restrict__ rays,
                                                uint32_t n_rays, DHit* __restrict__ hits) {
+    PT_SCENE_VIEW_FROM_PARAMS()
     extern __shared__ uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the frame kernel (STATS variant): cycles in refill / closest hit / shading, rounds, lane occupancy."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from path_tracing_amd import abi, scenes
+from tools.gpu_perf import SCENES
+for n in (sys.argv[1:] or list(SCENES)):
+    cfg, kw = SCENES[n]
+    scene = scenes.CONFIGS[cfg](**kw)
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        ctx.set_stats_detail(True)
+        ctx.render(scene.frame()); ctx.render(scene.frame())
+        s = ctx.stats()
+    tot = s["cycles_refill"] + s["cycles_trace"] + s["cycles_shade"]
+    print(f"{n}: ms {s['trace_ms']:.3f} rays {s['rays']} rounds {s['wave_rounds']} lanes/round {s['lane_rounds'] / max(s['wave_rounds'], 1):.1f} "
+          f"refill {100 * s['cycles_refill'] / tot:.1f}% trace {100 * s['cycles_trace'] / tot:.1f}% shade {100 * s['cycles_shade'] / tot:.1f}% "
+          f"cycles/round {tot / max(s['wave_rounds'], 1):.0f} xforms/ray {s['xforms'] / s['rays']:.2f} box/ray {s['box_tests'] / s['rays']:.2f} tri/ray {s['tri_tests'] / s['rays']:.2f} shades/ray {s['shades'] / s['rays']:.2f}")
