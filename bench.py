@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (invalidates the headline config)")
     ap.add_argument("--cpu-spp", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path with every rank on GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -87,10 +88,15 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = 0   # rehearsal on a one-GPU box: all ranks share device 0, the reduction goes through the host
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
 
     desc, make = WORKLOADS[args.workload]
     scene = make()
@@ -107,7 +113,12 @@ def main():
     def step():
         ctx.render_device(frame, out.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+            if args.backend == "nccl":
+                dist.all_reduce(out, op=dist.ReduceOp.SUM)
+            else:
+                host = out.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                out.copy_(host)
             out.mul_(1.0 / world)
 
     # detailed work counters from one untimed pass (slower kernel variant)
@@ -145,7 +156,8 @@ def main():
     t_max = dt
     rays_total = rays_local
     if world > 1:
-        buf = torch.tensor([dt, float(rays_local), float(st["rays_reference"]), float(st["paths"])], dtype=torch.float64, device=device)
+        buf = torch.tensor([dt, float(rays_local), float(st["rays_reference"]), float(st["paths"])], dtype=torch.float64,
+                           device=device if args.backend == "nccl" else "cpu")
         tmax = buf.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
@@ -163,6 +175,10 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         flops = sum(detail[k] * WORK[k][0] for k in WORK)
         abytes = sum(detail[k] * WORK[k][1] for k in WORK) + W * H * 16
+        # what must cross HBM at least once per frame: the scene arrays in, the image and the four aux planes out
+        scene_bytes = sum(int(a.nbytes) for a in (scene.objects, scene.meshes, scene.indices, scene.vertices, scene.materials,
+                                                  scene.textures, scene.texture_data))
+        compulsory = scene_bytes + W * H * 32
         achieved_tflops = flops / (k_ms * 1e-3) / 1e12
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
@@ -198,9 +214,9 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VALU_TFLOPS, 5),
                          "traffic": traffic,
                          "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": int(flops),
-                         "algorithmic_bytes_per_launch": int(abytes),
-                         "hbm": {"achieved_GBs": round(abytes / (k_ms * 1e-3) / 1e9, 2), "peak_GBs": PEAK_HBM_GBS,
-                                 "frac": round(abytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)},
+                         "on_chip_bytes_per_launch": int(abytes),
+                         "hbm": {"compulsory_bytes_per_launch": int(compulsory), "achieved_GBs": round(compulsory / (k_ms * 1e-3) / 1e9, 2),
+                                 "peak_GBs": PEAK_HBM_GBS, "frac": round(compulsory / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)},
                          "counts": {k: int(detail[k]) for k in WORK}},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,133 @@
+// raytrace_plugin.hpp — C++ mirror of the reference plugin's surface for its render pass, over the C ABI.
+//
+// Same names and argument meaning as the Rust side (reference src/lib.rs:1-7, src/shader.rs:35-213,
+// src/data.rs:15-97): RayTraceSettings, RayTraceMeta, RayTracePlugin{build,finish}, RayTraceNode::run.
+// The wgpu render pass the reference records in RayTraceNode::run is replaced by pt_render().
+// Error behaviour: like the reference, run() draws nothing (returns false) while the plugin is not ready
+// (src/shader.rs:133-145); where the reference would panic on unusable buffers (src/shader.rs:168-187) a
+// PtException carrying the library's error code is thrown on this side of the ABI.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pt_amd.h"
+
+namespace path_tracing {
+
+struct PtException : std::runtime_error {
+    int code;
+    PtException(int c, const std::string& m) : std::runtime_error("pt_amd error " + std::to_string(c) + ": " + m), code(c) {}
+};
+
+// reference src/data.rs:15-20 (#[derive(Default)]: all zero)
+struct RayTraceSettings {
+    uint32_t bounces = 0;
+    uint32_t samples = 0;
+    float sky_color[4] = {0, 0, 0, 0};  // LinearRgba
+};
+
+// the fields of bevy_render::view::View the shader reads (reference src/raytrace.wgsl:210-217)
+struct View {
+    float world_from_view[16];
+    float view_from_clip[16];
+    float viewport[4];  // x, y, width, height
+};
+
+// bevy_render::globals::Globals (only `time` is read, reference src/raytrace.wgsl:210)
+struct Globals {
+    float time = 0.0f;
+};
+
+// reference src/data.rs:83-97: the storage buffers the extract systems fill
+struct RayTraceMeta {
+    std::vector<PtObject> objects;
+    std::vector<uint32_t> emissives;  // bound but never read by the shader (src/query.wgsl:9); not uploaded
+    std::vector<PtMesh> meshes;
+    std::vector<uint32_t> indices;
+    std::vector<PtVertex> vertices;
+    std::vector<PtMaterial> materials;
+    std::vector<PtTexture> textures;
+    std::vector<float> texture_data;
+    bool meshes_dirty = true, materials_dirty = true, objects_dirty = true;
+};
+
+class RayTracePlugin;
+
+// reference src/shader.rs:111-214
+class RayTraceNode {
+public:
+    explicit RayTraceNode(RayTracePlugin* p) : plugin_(p) {}
+    // Renders the view into `target` (width*height*4 floats, row 0 on top). Returns false without touching
+    // `target` when the plugin is not ready or the camera has no settings.
+    bool run(const View& view, const Globals& globals, const RayTraceSettings* settings, std::vector<float>& target, uint32_t flags = 0);
+
+private:
+    RayTracePlugin* plugin_;
+};
+
+// reference src/shader.rs:35-104
+class RayTracePlugin {
+public:
+    explicit RayTracePlugin(int device = 0, uint32_t accel = PT_ACCEL_AUTO, uint32_t tie_rule = PT_TIE_REFERENCE)
+        : node(this), device_(device), accel_(accel), tie_(tie_rule) {}
+    ~RayTracePlugin() { if (ctx_) pt_destroy(ctx_); }
+    RayTracePlugin(const RayTracePlugin&) = delete;
+    RayTracePlugin& operator=(const RayTracePlugin&) = delete;
+
+    void build() { built_ = true; meta = RayTraceMeta(); }  // :38-95 inserts RayTraceMeta with empty buffers
+    void finish() {                                           // :97-103 creates the pipeline; here the device context
+        if (!built_) throw std::logic_error("RayTracePlugin::finish() before build()");
+        PtConfig cfg{};
+        cfg.abi_version = PT_ABI_VERSION;
+        cfg.device = device_;
+        cfg.accel = accel_;
+        cfg.tie_rule = tie_;
+        int rc = pt_create(&cfg, &ctx_);
+        if (rc != PT_OK) throw PtException(rc, pt_last_error(nullptr));
+    }
+    // the write_buffer calls of prepare_meshes / extract_materials / extract_textures / extract_visible
+    void prepare() {
+        check(meta.meshes_dirty ? pt_upload_meshes(ctx_, meta.meshes.data(), (uint32_t)meta.meshes.size(), meta.indices.data(),
+                                                   (uint32_t)meta.indices.size(), meta.vertices.data(), (uint32_t)meta.vertices.size()) : PT_OK);
+        check(meta.materials_dirty ? pt_upload_materials(ctx_, meta.materials.data(), (uint32_t)meta.materials.size(), meta.textures.data(),
+                                                         (uint32_t)meta.textures.size(), meta.texture_data.data(), (uint32_t)meta.texture_data.size()) : PT_OK);
+        check(meta.objects_dirty ? pt_upload_objects(ctx_, meta.objects.data(), (uint32_t)meta.objects.size()) : PT_OK);
+        meta.meshes_dirty = meta.materials_dirty = meta.objects_dirty = false;
+    }
+    bool ready() const { return ctx_ != nullptr; }
+    pt_ctx* context() const { return ctx_; }
+    void check(int rc) const { if (rc != PT_OK) throw PtException(rc, pt_last_error(ctx_)); }
+
+    RayTraceMeta meta;
+    RayTraceNode node;
+
+private:
+    int device_;
+    uint32_t accel_, tie_;
+    bool built_ = false;
+    pt_ctx* ctx_ = nullptr;
+};
+
+inline bool RayTraceNode::run(const View& view, const Globals& globals, const RayTraceSettings* settings, std::vector<float>& target, uint32_t flags) {
+    if (!plugin_->ready() || settings == nullptr) return false;
+    plugin_->prepare();
+    PtFrame f{};
+    for (int i = 0; i < 16; ++i) { f.world_from_view[i] = view.world_from_view[i]; f.view_from_clip[i] = view.view_from_clip[i]; }
+    f.width = (uint32_t)view.viewport[2];
+    f.height = (uint32_t)view.viewport[3];
+    f.time = globals.time;
+    f.flags = flags;
+    f.settings.bounces = settings->bounces;
+    f.settings.samples = settings->samples;
+    for (int i = 0; i < 4; ++i) f.settings.sky_color[i] = settings->sky_color[i];
+    f.part_index = 0;
+    f.part_count = 1;
+    target.resize((size_t)f.width * f.height * 4);
+    plugin_->check(pt_render(plugin_->context(), &f, target.data()));
+    return true;
+}
+
+}  // namespace path_tracing

@@ -377,3 +377,19 @@ def test_distributed_renderer_single_rank_device_tensor():
     worker = Path(__file__).resolve().parent / "gpu_torch_worker.py"
     r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cpp_host_mirror_cli(tmp_path):
+    """The compiled C++ mirror of the plugin surface (path_tracing_amd/host) renders the Cornell box through the C ABI."""
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "path_tracing_amd" / "host" / "pt_render_cli"
+    assert exe.exists(), "build() did not produce the C++ host demo"
+    out = tmp_path / "cornell.f32"
+    r = subprocess.run([str(exe), "48", "32", "3", "6", str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.fromfile(out, dtype=np.float32).reshape(32, 48, 4)
+    scene = scenes.cornell_box(48, 32, 3, 6)
+    ref = oracle_render(scene, scene.frame())["image"]
+    assert rrmse(img, ref) <= RRMSE_TOL
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
