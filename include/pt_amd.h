@@ -260,13 +260,16 @@ typedef struct PtStats {
     uint64_t tri_tests;     /* ray-triangle tests                               */
     uint64_t shades;        /* scatter evaluations (calculate_brdf)             */
     uint64_t hits;          /* queries that found a surface (hit_record built)  */
-    double trace_ms;        /* device time of the trace kernel(s), HIP events   */
+    double trace_ms;        /* device time of the frame's kernels, HIP events   */
+    double primary_ms;      /* of which the primary pass (k_primary)            */
+    double paths_ms;        /* and the path pass (k_paths)                      */
     double build_ms;        /* device time of the last TLAS build                */
     uint32_t trace_launches;/* kernel launches that trace_ms covers              */
     uint32_t accel_used;    /* bit 0: TLAS traversal, bit 1: BLAS traversal      */
     /* detail only: shader cycles summed over waves spent handing out pixels, in
      * closest hit, and in shading; rounds of the wave loop; lanes tracing per round */
     uint64_t cycles_refill, cycles_trace, cycles_shade, wave_rounds, lane_rounds;
+    uint64_t wave_life_sum, wave_life_max, waves; /* lifetime of the path kernel's waves, shader cycles */
 } PtStats;
 
 /* detail != 0 re-runs nothing; it only selects whether the next renders also

@@ -77,10 +77,12 @@ class PtConfig(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rays_reference", C.c_uint64), ("paths", C.c_uint64),
                 ("xforms", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("shades", C.c_uint64), ("hits", C.c_uint64), ("trace_ms", C.c_double), ("build_ms", C.c_double),
+                ("shades", C.c_uint64), ("hits", C.c_uint64), ("trace_ms", C.c_double), ("primary_ms", C.c_double), ("paths_ms", C.c_double),
+                ("build_ms", C.c_double),
                 ("trace_launches", C.c_uint32), ("accel_used", C.c_uint32),
                 ("cycles_refill", C.c_uint64), ("cycles_trace", C.c_uint64), ("cycles_shade", C.c_uint64),
-                ("wave_rounds", C.c_uint64), ("lane_rounds", C.c_uint64)]
+                ("wave_rounds", C.c_uint64), ("lane_rounds", C.c_uint64),
+                ("wave_life_sum", C.c_uint64), ("wave_life_max", C.c_uint64), ("waves", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

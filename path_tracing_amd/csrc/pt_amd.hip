@@ -13,7 +13,7 @@
 
 #include "../../include/pt_amd.h"
 #include "pt_build.h"
-#include "pt_trace.h"
+#include "pt_kernels.h"
 
 static_assert(sizeof(DMaterial) == sizeof(PtMaterial) && sizeof(DTexture) == sizeof(PtTexture), "wire == device");
 static_assert(sizeof(WObject) == sizeof(PtObject) && sizeof(WMesh) == sizeof(PtMesh) && sizeof(WVertex) == sizeof(PtVertex), "wire");
@@ -48,7 +48,7 @@ struct pt_ctx {
     PtConfig cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evb0 = nullptr, evb1 = nullptr;
+    hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr, evb0 = nullptr, evb1 = nullptr;
     std::string err;
     char info[256] = {0};
 
@@ -62,7 +62,7 @@ struct pt_ctx {
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors;
     // frame outputs
-    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits;
+    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
@@ -75,8 +75,8 @@ struct pt_ctx {
     std::vector<PtObject> h_objects;  // kept so that a mesh re-upload can rebuild the instance data
 
     uint32_t n_cus = 256;
-    uint32_t chunk_pixels = 64;   // see FrameParams::chunk
-    uint32_t refill_min = 0;      // see FrameParams::refill_min; 0 = choose per scene
+    uint32_t chunk_pixels = 64;   // see PathParams::chunk
+    uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
     uint32_t aux_w = 0, aux_h = 0;
     uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
     bool stats_detail = false;
@@ -180,6 +180,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
         if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->evm);
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb0);
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb1);
         if (e == hipSuccess) e = ctx->d_counters.ensure(sizeof(DCounters));
@@ -207,10 +208,11 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
-                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits};
+                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evm) (void)hipEventDestroy(ctx->evm);
     if (ctx->evb0) (void)hipEventDestroy(ctx->evb0);
     if (ctx->evb1) (void)hipEventDestroy(ctx->evb1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -526,8 +528,12 @@ int finish_timing(pt_ctx* ctx) {
     PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     DCounters c;
     PT_HIP(ctx, hipMemcpy(&c, ctx->d_counters.p, sizeof c, hipMemcpyDeviceToHost));
+    float ms_primary = 0.0f;
+    PT_HIP(ctx, hipEventElapsedTime(&ms_primary, ctx->ev0, ctx->evm));
     ctx->stats.trace_ms = ms;
-    ctx->stats.trace_launches = 1;
+    ctx->stats.primary_ms = ms_primary;
+    ctx->stats.paths_ms = ms - ms_primary;
+    ctx->stats.trace_launches = 2;
     ctx->stats.rays = c.rays;
     ctx->stats.xforms = c.xforms;
     ctx->stats.box_tests = c.box_tests;
@@ -539,6 +545,9 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.cycles_shade = c.cyc_shade;
     ctx->stats.wave_rounds = c.rounds;
     ctx->stats.lane_rounds = c.lane_rounds;
+    ctx->stats.wave_life_sum = c.wave_life_sum;
+    ctx->stats.wave_life_max = c.wave_life_max;
+    ctx->stats.waves = c.waves;
     ctx->stats.paths = ctx->last_paths;
     ctx->stats.rays_reference = c.rays + ctx->last_primary;
     ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u);
@@ -582,18 +591,6 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     fp.tiles_y = div_up(f->height, 8);
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     fp.n_local_tiles = (f->part_index < n_tiles) ? (n_tiles - f->part_index + pc - 1) / pc : 0u;
-    fp.chunk = ctx->chunk_pixels;
-    // few objects: keep a wave on one tile at a time (coherent candidates); many objects: keep every lane busy
-    fp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
-    {   // a stride near 0.618 * n that is coprime to n
-        uint32_t n = std::max(fp.n_local_tiles, 1u);
-        uint32_t sdr = (uint32_t)((double)n * 0.6180339887) | 1u;
-        if (std::getenv("PT_AMD_NO_SCATTER") || n < 8) sdr = 1;
-        auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
-        while (gcd(sdr, n) != 1) sdr += 2;
-        fp.tile_stride = sdr % n ? sdr % n : 1;
-    }
-
     PT_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
     if (pc > 1) {
         PT_HIP(ctx, hipMemsetAsync(out, 0, 16 * n_pix, s));
@@ -602,25 +599,57 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_t.p, 0, 4 * n_pix, s));
         PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_rays.p, 0, 4 * n_pix, s));
     }
+    // path list: at most one entry per pixel of this partition
+    PT_HIP(ctx, ctx->d_paths.ensure(sizeof(PathRec) * (size_t)fp.n_local_tiles * 64));
     SceneView sv = make_view(ctx);
     const uint32_t depth = stack_depth_needed(ctx);
-    const size_t lds = (size_t)4 * (depth + PT_LANE_SLOTS) * 64 * sizeof(uint32_t);
     const bool st = ctx->stats_detail;
-    // persistent waves: as many workgroups as fit on the chip at once (or fewer for small frames); they pull pixels
-    // from a counter until the frame is done
-    using RenderFn = void (*)(PT_SCENE_PARAMS, FrameParams, uint32_t, float4*, uint32_t*, uint32_t*, float*, uint32_t*, DCounters*);
-    RenderFn fn = ctx->use_tlas ? (st ? k_render<true, true> : k_render<true, false>) : (st ? k_render<false, true> : k_render<false, false>);
-    int per_cu = 0;
-    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds));
-    if (per_cu < 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: the frame kernel does not fit on a compute unit with this traversal stack");
-    if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
-    const uint32_t resident = (uint32_t)per_cu * ctx->n_cus;
-    const uint32_t grid = std::min(div_up(fp.n_local_tiles, 4), resident);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    uint32_t* ao = ctx->d_aux_obj.as<uint32_t>();
+    uint32_t* af = ctx->d_aux_flat.as<uint32_t>();
+    float* at = ctx->d_aux_t.as<float>();
+    uint32_t* ar = ctx->d_aux_rays.as<uint32_t>();
+    PathRec* recs = ctx->d_paths.as<PathRec>();
+    DCounters* dc = ctx->d_counters.as<DCounters>();
+
     PT_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    if (grid) {
-        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, reinterpret_cast<float4*>(out), ctx->d_aux_obj.as<uint32_t>(),
-                                  ctx->d_aux_flat.as<uint32_t>(), ctx->d_aux_t.as<float>(), ctx->d_aux_rays.as<uint32_t>(),
-                                  ctx->d_counters.as<DCounters>());
+    // 1. primary pass: one wave per tile
+    {
+        const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t);
+        const uint32_t grid = div_up(fp.n_local_tiles, 4);
+        if (grid) {
+            if (ctx->use_tlas) {
+                if (st) k_primary<true, true><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, o4, ao, af, at, ar, recs, dc);
+                else k_primary<true, false><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, o4, ao, af, at, ar, recs, dc);
+            } else {
+                if (st) k_primary<false, true><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, o4, ao, af, at, ar, recs, dc);
+                else k_primary<false, false><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, o4, ao, af, at, ar, recs, dc);
+            }
+            PT_HIP(ctx, hipGetLastError());
+        }
+    }
+    PT_HIP(ctx, hipEventRecord(ctx->evm, s));
+    // 2. path pass: persistent waves, as many workgroups as fit on the chip at once (fewer for small frames); they
+    //    pull list entries from a counter until the list is exhausted
+    if (fp.bounces > 0 && fp.samples > 0 && fp.n_local_tiles) {
+        PathParams pp;
+        pp.origin[0] = fp.wfv[12]; pp.origin[1] = fp.wfv[13]; pp.origin[2] = fp.wfv[14];
+        pp.sky[0] = fp.sky[0]; pp.sky[1] = fp.sky[1]; pp.sky[2] = fp.sky[2];
+        pp.bounces = fp.bounces;
+        pp.samples = fp.samples;
+        pp.chunk = ctx->chunk_pixels;
+        // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
+        pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
+        const size_t lds = (size_t)4 * (depth + PT_LANE_SLOTS) * 64 * sizeof(uint32_t);
+        using PathsFn = void (*)(PT_SCENE_PARAMS, PathParams, uint32_t, const PathRec*, float4*, uint32_t*, DCounters*);
+        PathsFn fn = ctx->use_tlas ? (st ? k_paths<true, true> : k_paths<true, false>) : (st ? k_paths<false, true> : k_paths<false, false>);
+        int per_cu = 0;
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds));
+        if (per_cu < 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: the path kernel does not fit on a compute unit with this traversal stack");
+        if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
+        const uint32_t grid = std::min(div_up(fp.n_local_tiles, 4), (uint32_t)per_cu * ctx->n_cus);
+        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u\n", per_cu, grid, lds, depth, pp.chunk, pp.refill_min);
+        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), pp, depth, recs, o4, ar, dc);
         PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, s));

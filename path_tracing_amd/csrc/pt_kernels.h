@@ -1,0 +1,426 @@
+// pt_kernels.h — the kernels of a frame.
+//
+//   k_primary  one lane per pixel: seed, camera ray, closest hit (the query stage, reference src/query.wgsl:55-147,
+//              for the ray of src/raytrace.wgsl:212-217). The primary ray of a pixel is the same for all of its
+//              samples (src/raytrace.wgsl:223 restarts from the same origin/direction, no jitter), so it is traced
+//              once. Pixels whose primary hit ends every path at once (miss, or black-albedo emitter) are finished
+//              here; every other pixel is appended, with its hit record, to the path list.
+//   k_paths    persistent waves over the path list: the sample x bounce loop of src/raytrace.wgsl:221-273 with the
+//              reference's per-pixel order of RNG draws and f32 accumulations, one pixel per lane at a time.
+//   k_query    hit_all for a batch of rays (tests, tools).
+//   k_accumulate  running mean over frames.
+#pragma once
+
+#include "pt_trace.h"
+
+#ifndef PT_PATHS_MIN_WAVES
+#define PT_PATHS_MIN_WAVES 4   // waves per SIMD k_paths is compiled for (caps its VGPR allocation)
+#endif
+
+// One entry of the path list: everything k_paths needs to run a pixel. 64 B.
+struct PathRec {
+    float4 a;  // bits(pix), bits(object of the primary hit), hit uv.x, hit uv.y
+    float4 b;  // hit p.xyz, hit n.x
+    float4 c;  // hit n.y, hit n.z, primary dir.x, primary dir.y
+    float4 d;  // primary dir.z, bits(rng seed x), bits(seed y), bits(seed z)
+};
+static_assert(sizeof(PathRec) == 64, "PathRec");
+
+struct PathParams {
+    float origin[3];
+    float sky[3];
+    uint32_t bounces, samples;
+    uint32_t chunk;       // path numbers a wave takes from the work counter at a time (multiple of 64)
+    uint32_t refill_min;  // a wave hands out new pixels only when at least this many of its lanes are idle (1..64)
+};
+
+PT_DEV uint32_t wave_sum_u32(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// True when a path that reaches this hit stops there without scattering: a miss, or a surface whose albedo is
+// black (src/raytrace.wgsl:245-248). `c` is what the path adds: fma(ray_color = 1, emissive or sky, color = 0).
+PT_DEV bool primary_is_terminal(const SceneView& sc, const HitInfo& h, v3 sky, v3& c) {
+    c = sky;
+    if (h.obj != PT_NONE) {
+        const DMaterial m = sc.materials[sc.objects[h.obj].mat];
+        const v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+        if (!(dot3(alb, alb) < PT_EPSILON)) return false;
+        c = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
+        if (m.emissive_texture != PT_NONE) c = sample_texture(sc, m.emissive_texture, h.u, h.v);
+    }
+    c = V3(pt_fma(1.0f, c.x, 0.0f), pt_fma(1.0f, c.y, 0.0f), pt_fma(1.0f, c.z, 0.0f));
+    return true;
+}
+
+// ---- primary pass: one wave per 8x8 pixel tile, four tiles per workgroup --------------------------------------
+template <bool TLAS, bool STATS>
+__global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, FrameParams fp, uint32_t stack_depth, float4* __restrict__ out,
+                                                 uint32_t* __restrict__ aux_obj, uint32_t* __restrict__ aux_flat,
+                                                 float* __restrict__ aux_t, uint32_t* __restrict__ aux_rays,
+                                                 PathRec* __restrict__ recs, DCounters* __restrict__ counters) {
+    PT_SCENE_VIEW_FROM_PARAMS()
+    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t local_tile = blockIdx.x * 4 + wave;
+    if (local_tile >= fp.n_local_tiles) return;  // wave-uniform
+    LdsStack stk;
+    stk.base = &s_mem[wave * stack_depth * 64 + lane];
+
+    const uint32_t tile = local_tile * fp.part_count + fp.part_index;
+    const uint32_t ty = tile / fp.tiles_x, tx = tile - ty * fp.tiles_x;
+    const uint32_t px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+    const bool valid = px < fp.width && py < fp.height;
+    const uint32_t pix = py * fp.width + px;
+
+    // fullscreen triangle at the pixel centre; src/raytrace.wgsl:210-217
+    const float W = (float)fp.width, H = (float)fp.height;
+    const float uvx = pt_div((float)px + 0.5f, W), uvy = pt_div((float)py + 0.5f, H);
+    const float tp1 = fp.time + 1.0f;
+    const float sx = (uvx * W) * tp1, sy = (uvy * H) * tp1;
+    const uint32_t seed_x = pt_f2u(sx), seed_y = pt_f2u(sy), seed_z = seed_x ^ seed_y;
+    const float dx = uvx * 2.0f - 1.0f;
+    const float dy = (uvy * 2.0f - 1.0f) * -1.0f;
+    const v3 origin = V3(fp.wfv[12], fp.wfv[13], fp.wfv[14]);
+    v3 temp = V3(pt_fma(fp.vfc[4], dy, fp.vfc[0] * dx) + fp.vfc[8] + fp.vfc[12],
+                 pt_fma(fp.vfc[5], dy, fp.vfc[1] * dx) + fp.vfc[9] + fp.vfc[13],
+                 pt_fma(fp.vfc[6], dy, fp.vfc[2] * dx) + fp.vfc[10] + fp.vfc[14]);
+    temp = normalize3(temp);
+    const v3 dir0 = V3(pt_fma(fp.wfv[8], temp.z, pt_fma(fp.wfv[4], temp.y, fp.wfv[0] * temp.x)),
+                       pt_fma(fp.wfv[9], temp.z, pt_fma(fp.wfv[5], temp.y, fp.wfv[1] * temp.x)),
+                       pt_fma(fp.wfv[10], temp.z, pt_fma(fp.wfv[6], temp.y, fp.wfv[2] * temp.x)));
+
+    const uint32_t samples = fp.samples;
+    const float ns = (float)samples;
+    if (!(fp.bounces > 0 && samples > 0)) {
+        // no ray is ever traced: `samples` additions of zero, then the division (0/0 when samples == 0)
+        if (valid) {
+            out[pix] = make_float4(pt_div(0.0f, ns), pt_div(0.0f, ns), pt_div(0.0f, ns), 1.0f);
+            aux_obj[pix] = PT_NONE; aux_flat[pix] = PT_NONE; aux_t[pix] = PT_T_MAX; aux_rays[pix] = 0u;
+        }
+        return;
+    }
+
+    LaneCounters cnt = {0, 0, 0, 0, 0};
+    Best b;
+    closest_hit<TLAS, STATS>(sc, origin, dir0, valid, b, stk, cnt);
+    bool to_list = false;
+    HitInfo h;
+    h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
+    if (valid) {
+        if (STATS && b.obj != PT_NONE) cnt.hits++;
+        h = finalize_hit(sc, origin, dir0, b);
+        aux_obj[pix] = b.obj;
+        aux_flat[pix] = (b.obj != PT_NONE) ? sc.objects[b.obj].tri_base + b.tri : PT_NONE;
+        aux_t[pix] = b.t;
+        v3 c;
+        if (primary_is_terminal(sc, h, V3(fp.sky[0], fp.sky[1], fp.sky[2]), c)) {
+            v3 pixel_color = V3(0, 0, 0);
+            for (uint32_t k = 0; k < samples; ++k) pixel_color = add3(pixel_color, c);
+            out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
+            aux_rays[pix] = samples;  // the reference traces the primary ray once per sample
+        } else {
+            to_list = true;
+        }
+    }
+    // append this tile's surviving pixels to the path list: one atomic per wave
+    const unsigned long long m = __ballot(to_list);
+    if (m != 0ull) {
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&counters->n_paths, (uint32_t)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (to_list) {
+            PathRec r;
+            r.a = make_float4(__uint_as_float(pix), __uint_as_float(h.obj), h.u, h.v);
+            r.b = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
+            r.c = make_float4(h.n.y, h.n.z, dir0.x, dir0.y);
+            r.d = make_float4(dir0.z, __uint_as_float(seed_x), __uint_as_float(seed_y), __uint_as_float(seed_z));
+            recs[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        }
+    }
+    const uint32_t r = wave_sum_u32(valid ? 1u : 0u);
+    if (lane == 0) atomicAdd(&counters->rays, (unsigned long long)r);
+    if (STATS) {
+        const uint32_t a = wave_sum_u32(cnt.xforms), bb = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
+                       e = wave_sum_u32(cnt.hits);
+        if (lane == 0) {
+            atomicAdd(&counters->xforms, (unsigned long long)a);
+            atomicAdd(&counters->box_tests, (unsigned long long)bb);
+            atomicAdd(&counters->tri_tests, (unsigned long long)c);
+            atomicAdd(&counters->hits, (unsigned long long)e);
+        }
+    }
+}
+
+// ---- path pass -----------------------------------------------------------------------------------------------
+// Persistent waves with per-lane refill. A lane owns one pixel at a time; across pixels nothing is shared. Every
+// round of the loop
+//   A. hands a new list entry to each idle lane (the wave owns a chunk of consecutive entries, i.e. pixels of a
+//      few neighbouring tiles, and takes the next chunk from a global counter when it runs out),
+//   B. shades: every lane that holds a hit shades it; a lane whose path ends moves on to the pixel's next sample
+//      and shades the cached primary hit right away, until it holds a new ray or the pixel is complete,
+//   C. traces one ray for every lane that has one.
+// So the closest-hit code always runs with (nearly) all lanes, however uneven the path lengths are.
+#define PT_ST_IDLE 0u
+#define PT_ST_SHADE 1u
+#define PT_ST_TRACE 2u
+#define PT_LANE_SLOTS 12  // per-lane LDS words: primary hit record (9) + primary direction (3)
+
+template <bool TLAS, bool STATS>
+__global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, PathParams pp, uint32_t stack_depth,
+                                                                    const PathRec* __restrict__ recs, float4* __restrict__ out,
+                                                                    uint32_t* __restrict__ aux_rays, DCounters* __restrict__ counters) {
+    PT_SCENE_VIEW_FROM_PARAMS()
+    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes] stacks, then [4 waves][PT_LANE_SLOTS][64 lanes]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    LdsStack stk;
+    stk.base = &s_mem[wave * stack_depth * 64 + lane];
+    float* slot = reinterpret_cast<float*>(&s_mem[4 * stack_depth * 64 + wave * PT_LANE_SLOTS * 64 + lane]);  // slot[k*64]
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    const uint32_t total = counters->n_paths;  // written by k_primary, which ran before on the same stream
+    const v3 origin = V3(pp.origin[0], pp.origin[1], pp.origin[2]);
+    const v3 sky = V3(pp.sky[0], pp.sky[1], pp.sky[2]);
+    const uint32_t bounces = pp.bounces, samples = pp.samples;
+    const float ns = (float)samples;
+
+    LaneCounters cnt = {0, 0, 0, 0, 0};
+    uint32_t lane_rays = 0;
+    unsigned long long t_begin = 0;
+    if (STATS) t_begin = __builtin_amdgcn_s_memtime();
+
+    uint32_t st = PT_ST_IDLE, pix = 0, sample = 0, bounce = 0, nrays = 0;
+    Rng rng = {0, 0, 0};
+    v3 rpos = origin, rdir = V3(0, 0, 1);
+    v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0), pixel_color = V3(0, 0, 0);
+    HitInfo h;
+    h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
+    bool exhausted = false;                  // wave-uniform: the global counter has run out
+    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: this wave's current chunk of list entries
+    unsigned long long cyc_refill = 0, cyc_trace = 0, cyc_shade = 0, n_rounds = 0, lane_rounds = 0;  // STATS only
+
+    for (;;) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if (STATS) t0 = __builtin_amdgcn_s_memtime();
+        // ---- A. refill idle lanes ---------------------------------------------------------------------------
+        {
+            bool need = st == PT_ST_IDLE;
+            unsigned long long m = __ballot(need);
+            if ((uint32_t)__popcll(m) < pp.refill_min) m = 0ull;  // wait until enough lanes are free: newcomers share a tile
+            while (m != 0ull && !exhausted) {
+                if (chunk_next == chunk_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&counters->next_path, pp.chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total) {
+                        exhausted = true;
+                        break;
+                    }
+                    chunk_next = base;
+                    chunk_end = (total - base < pp.chunk) ? total : base + pp.chunk;
+                }
+                const uint32_t avail = chunk_end - chunk_next;
+                const uint32_t want = (uint32_t)__popcll(m);
+                const uint32_t take = want < avail ? want : avail;
+                const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
+                if (need && rank < take) {
+                    need = false;
+                    const PathRec* r = &recs[chunk_next + rank];
+                    const float4 ra = r->a, rb = r->b, rc = r->c, rd = r->d;
+                    pix = __float_as_uint(ra.x);
+                    h.obj = __float_as_uint(ra.y);
+                    h.u = ra.z; h.v = ra.w;
+                    h.p = V3(rb.x, rb.y, rb.z);
+                    h.n = V3(rb.w, rc.x, rc.y);
+                    rdir = V3(rc.z, rc.w, rd.x);
+                    rng.x = __float_as_uint(rd.y); rng.y = __float_as_uint(rd.z); rng.z = __float_as_uint(rd.w);
+                    slot[0] = ra.y;
+                    slot[1 * 64] = h.p.x; slot[2 * 64] = h.p.y; slot[3 * 64] = h.p.z;
+                    slot[4 * 64] = h.n.x; slot[5 * 64] = h.n.y; slot[6 * 64] = h.n.z;
+                    slot[7 * 64] = h.u; slot[8 * 64] = h.v;
+                    slot[9 * 64] = rdir.x; slot[10 * 64] = rdir.y; slot[11 * 64] = rdir.z;
+                    sample = 0; bounce = 0;
+                    nrays = 1;  // the primary ray, traced by k_primary
+                    pixel_color = V3(0, 0, 0);
+                    ray_color = V3(1, 1, 1);
+                    color = V3(0, 0, 0);
+                    rpos = origin;
+                    st = PT_ST_SHADE;
+                }
+                chunk_next += take;
+                m = __ballot(need);
+            }
+        }
+        if (!__any(st != PT_ST_IDLE)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- B. shade (src/raytrace.wgsl:229-270) and advance (sample, bounce) ----------------------------------
+        if (STATS) t1 = __builtin_amdgcn_s_memtime();
+        bool pending = st == PT_ST_SHADE;
+        while (__any(pending)) {
+            if (pending) {
+                bool end_path = false;
+                if (h.obj != PT_NONE) {
+                    const DMaterial m = sc.materials[sc.objects[h.obj].mat];
+                    v3 emissive = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
+                    if (m.emissive_texture != PT_NONE) emissive = sample_texture(sc, m.emissive_texture, h.u, h.v);
+                    color = V3(pt_fma(ray_color.x, emissive.x, color.x), pt_fma(ray_color.y, emissive.y, color.y),
+                               pt_fma(ray_color.z, emissive.z, color.z));
+                    const v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+                    if (dot3(alb, alb) < PT_EPSILON) {
+                        end_path = true;
+                    } else {
+                        v3 N = h.n;
+                        if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
+                        v3 ndir, bcol;
+                        if (STATS) cnt.shades++;
+                        calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
+                        rdir = ndir;
+                        rpos = madd3(h.p, rdir, 0.001f);
+                        ray_color = mul3(ray_color, bcol);
+                        const float p = pt_max(ray_color.x, pt_max(ray_color.y, ray_color.z));
+                        bounce++;
+                        if (p < PT_EPSILON || bounce >= bounces) end_path = true;
+                    }
+                } else {
+                    color = V3(pt_fma(ray_color.x, sky.x, color.x), pt_fma(ray_color.y, sky.y, color.y),
+                               pt_fma(ray_color.z, sky.z, color.z));
+                    end_path = true;
+                }
+                if (end_path) {
+                    pixel_color = add3(pixel_color, color);
+                    sample++;
+                    if (sample >= samples) {
+                        out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
+                        // queries the reference would have run: it re-traces the primary ray for every sample
+                        aux_rays[pix] = nrays + samples - 1u;
+                        st = PT_ST_IDLE;
+                        pending = false;
+                    } else {
+                        bounce = 0;
+                        rpos = origin;
+                        rdir = V3(slot[9 * 64], slot[10 * 64], slot[11 * 64]);
+                        ray_color = V3(1, 1, 1);
+                        color = V3(0, 0, 0);
+                        h.obj = __float_as_uint(slot[0]);
+                        h.p = V3(slot[1 * 64], slot[2 * 64], slot[3 * 64]);
+                        h.n = V3(slot[4 * 64], slot[5 * 64], slot[6 * 64]);
+                        h.u = slot[7 * 64];
+                        h.v = slot[8 * 64];
+                    }
+                } else {
+                    st = PT_ST_TRACE;
+                    pending = false;
+                }
+            }
+        }
+
+        // ---- C. trace ---------------------------------------------------------------------------------------
+        if (STATS) {
+            t2 = __builtin_amdgcn_s_memtime();
+            n_rounds++;
+            lane_rounds += (unsigned long long)__popcll(__ballot(st == PT_ST_TRACE));
+        }
+        if (__any(st == PT_ST_TRACE)) {
+            const bool tracing = st == PT_ST_TRACE;
+            Best b;
+            closest_hit<TLAS, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
+            if (tracing) {
+                nrays++;
+                lane_rays++;
+                if (STATS && b.obj != PT_NONE) cnt.hits++;
+                h = finalize_hit(sc, rpos, rdir, b);
+                st = PT_ST_SHADE;
+            }
+        }
+        if (STATS) {
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            cyc_refill += t1 - t0;
+            cyc_shade += t2 - t1;
+            cyc_trace += t3 - t2;
+        }
+    }
+
+    const uint32_t r = wave_sum_u32(lane_rays);
+    if (lane == 0 && r) atomicAdd(&counters->rays, (unsigned long long)r);
+    if (STATS) {
+        const uint32_t a = wave_sum_u32(cnt.xforms), b = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
+                       d = wave_sum_u32(cnt.shades), e = wave_sum_u32(cnt.hits);
+        if (lane == 0) {
+            const unsigned long long life = __builtin_amdgcn_s_memtime() - t_begin;
+            atomicAdd(&counters->wave_life_sum, life);
+            atomicMax(&counters->wave_life_max, life);
+            if (n_rounds) atomicAdd(&counters->waves, 1ull);
+            atomicAdd(&counters->cyc_refill, cyc_refill);
+            atomicAdd(&counters->cyc_trace, cyc_trace);
+            atomicAdd(&counters->cyc_shade, cyc_shade);
+            atomicAdd(&counters->rounds, n_rounds);
+            atomicAdd(&counters->lane_rounds, lane_rounds);
+            atomicAdd(&counters->hits, (unsigned long long)e);
+            atomicAdd(&counters->xforms, (unsigned long long)a);
+            atomicAdd(&counters->box_tests, (unsigned long long)b);
+            atomicAdd(&counters->tri_tests, (unsigned long long)c);
+            atomicAdd(&counters->shades, (unsigned long long)d);
+        }
+    }
+}
+
+// ---- hit_all for a batch of rays (the query stage on its own) ---------------------------------------------------
+struct DRay {
+    float pos[3];
+    float dir[3];
+};
+struct DHit {
+    uint32_t object, triangle, flat_id;
+    float t;
+    float p[3], n[3], uv[2];
+};
+
+template <bool TLAS>
+__global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_depth, const DRay* __restrict__ rays,
+                                               uint32_t n_rays, DHit* __restrict__ hits) {
+    PT_SCENE_VIEW_FROM_PARAMS()
+    extern __shared__ uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    LdsStack stk;
+    stk.base = &s_stack[wave * stack_depth * 64 + lane];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n_rays;
+    v3 ro = V3(0, 0, 0), rd = V3(0, 0, 1);
+    if (valid) {
+        ro = V3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
+        rd = V3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+    }
+    LaneCounters cnt = {0, 0, 0, 0, 0};
+    Best b;
+    closest_hit<TLAS, false>(sc, ro, rd, valid, b, stk, cnt);
+    if (!valid) return;
+    HitInfo h = finalize_hit(sc, ro, rd, b);
+    DHit o;
+    o.object = b.obj;
+    o.t = b.t;
+    if (b.obj != PT_NONE) {
+        o.triangle = b.tri;
+        o.flat_id = sc.objects[b.obj].tri_base + b.tri;
+    } else {
+        o.triangle = PT_NONE;
+        o.flat_id = PT_NONE;
+    }
+    o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+    o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
+    o.uv[0] = h.u; o.uv[1] = h.v;
+    hits[i] = o;
+}
+
+// acc += frame; out = acc / n_frames  (radiance accumulation across frames; RGB only, A stays 1)
+__global__ void k_accumulate(float4* __restrict__ acc, float4* __restrict__ img, uint32_t n_pixels, float n_frames) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 a = acc[i], f = img[i];
+    a.x += f.x; a.y += f.y; a.z += f.z; a.w = 1.0f;
+    acc[i] = a;
+    img[i] = make_float4(pt_div(a.x, n_frames), pt_div(a.y, n_frames), pt_div(a.z, n_frames), 1.0f);
+}

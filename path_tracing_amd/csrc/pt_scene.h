@@ -134,9 +134,6 @@ struct FrameParams {
     uint32_t part_index, part_count;
     uint32_t tiles_x, tiles_y;
     uint32_t n_local_tiles;
-    uint32_t chunk;   // pixel numbers a wave takes from the work counter at a time (multiple of 64)
-    uint32_t tile_stride;   // tile visiting order: k-th tile visited = (k * tile_stride) % n_local_tiles, gcd(tile_stride, n_local_tiles) == 1
-    uint32_t refill_min;  // a wave hands out new pixels only when at least this many of its lanes are idle (1..64)
 };
 
 // Work counters accumulated by the trace kernels (one atomic per wave and counter).
@@ -147,9 +144,9 @@ struct DCounters {
     unsigned long long tri_tests;
     unsigned long long shades;
     unsigned long long hits;
-    unsigned int next_pixel;   // work queue head of the frame kernel: next unassigned pixel of this launch
-    unsigned int _pad0;
+    unsigned int n_paths;      // entries k_primary appended to the path list
+    unsigned int next_path;    // work queue head of k_paths: next unassigned list entry
     unsigned long long _pad[1];
     // phase clocks of the frame kernel (shader cycles summed over waves), STATS variant only
-    unsigned long long cyc_refill, cyc_trace, cyc_shade, rounds, lane_rounds, _pad2[3];
+    unsigned long long cyc_refill, cyc_trace, cyc_shade, rounds, lane_rounds, wave_life_sum, wave_life_max, waves;
 };

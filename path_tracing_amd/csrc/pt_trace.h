@@ -1,6 +1,6 @@
-// pt_trace.h — the two device stages of the hot path:
-//   closest_hit_*  replaces hit_all / hit_mesh / hit_box   (reference src/query.wgsl:55-147)
-//   k_render       replaces fragment() and its helpers      (reference src/raytrace.wgsl:60-277)
+// pt_trace.h — device functions of the two stages of the hot path:
+//   closest_hit_*, object_test, tri_test, hit_box_exact   replace hit_all / hit_mesh / hit_box (reference src/query.wgsl:55-147)
+//   calculate_brdf, sample_texture                        replace the shading helpers          (reference src/raytrace.wgsl:88-203)
 //
 // Closest hit keeps the reference's per-candidate arithmetic exactly (ray moved to the
 // object's local space with world_to_local, the quirky mesh-AABB gate, Moeller-Trumbore
@@ -13,11 +13,6 @@
 #pragma once
 
 #include "pt_scene.h"
-
-// Minimum waves per SIMD the render kernel is compiled for (caps its VGPR allocation).
-#ifndef PT_RENDER_MIN_WAVES
-#define PT_RENDER_MIN_WAVES 4
-#endif
 
 struct Best {
     float t;
@@ -374,343 +369,4 @@ PT_DEV void calculate_brdf(const SceneView& sc, Rng& rng, v3 ray_dir, v3 N, floa
     float fd = (f_schlick_1(f90, NdotL) * f_schlick_1(f90, NdotV)) * (1.0f / PT_PI);
     out_dir = L;
     out_color = scale3(scale3(albedo, fd), PT_PI);
-}
-
-PT_DEV uint32_t wave_sum_u32(uint32_t v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// ---- the frame kernel ---------------------------------------------------------------
-// Persistent waves with per-lane refill. A lane owns one pixel at a time and keeps the reference's per-pixel
-// order of RNG draws and of every f32 accumulation (`for sample { for bounce {...} }`, src/raytrace.wgsl:221-273);
-// across pixels nothing is shared. Every round of the loop below
-//   A. hands a new pixel to each idle lane (one wave-aggregated atomic on a global pixel counter; pixels are
-//      numbered tile by tile so that a wave's lanes stay on neighbouring pixels),
-//   B. traces one ray for every lane that has one (primary or secondary - same code),
-//   C. shades: a lane whose path ends moves on to the pixel's next sample and shades the cached primary hit
-//      right away, until it holds a new ray or the pixel is complete.
-// So the closest-hit code always runs with (nearly) all lanes, however uneven the path lengths are.
-// The primary ray is identical for every sample of a pixel (src/raytrace.wgsl:223 restarts from the same
-// origin/direction, no jitter), so its closest hit is traced once per pixel and its hit record kept in LDS.
-#define PT_ST_IDLE 0u
-#define PT_ST_TRACE 1u
-#define PT_ST_SHADE 2u
-#define PT_LANE_SLOTS 12  // per-lane LDS words: cached primary hit record (9) + primary direction (3)
-
-template <bool TLAS, bool STATS>
-__global__ __launch_bounds__(256, PT_RENDER_MIN_WAVES) void k_render(PT_SCENE_PARAMS, FrameParams fp, uint32_t stack_depth,
-                                                                     float4* __restrict__ out, uint32_t* __restrict__ aux_obj,
-                                                                     uint32_t* __restrict__ aux_flat, float* __restrict__ aux_t,
-                                                                     uint32_t* __restrict__ aux_rays, DCounters* __restrict__ counters) {
-    PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes] stacks, then [4 waves][PT_LANE_SLOTS][64 lanes]
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    LdsStack stk;
-    stk.base = &s_mem[wave * stack_depth * 64 + lane];
-    float* slot = reinterpret_cast<float*>(&s_mem[4 * stack_depth * 64 + wave * PT_LANE_SLOTS * 64 + lane]);  // slot[k*64]
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-    const float W = (float)fp.width, H = (float)fp.height;
-    const float tp1 = fp.time + 1.0f;
-    const v3 origin = V3(fp.wfv[12], fp.wfv[13], fp.wfv[14]);
-    const uint32_t bounces = fp.bounces, samples = fp.samples;
-    const float ns = (float)samples;
-    const v3 sky = V3(fp.sky[0], fp.sky[1], fp.sky[2]);
-    const bool any_rays = bounces > 0 && samples > 0;
-    const uint32_t total = fp.n_local_tiles * 64u;
-
-    LaneCounters cnt = {0, 0, 0, 0, 0};
-    uint32_t wave_rays = 0;  // per lane, summed at the end
-
-    // per-pixel state
-    uint32_t st = PT_ST_IDLE, pix = 0, sample = 0, bounce = 0, nrays = 0;
-    bool primary_pending = false;
-    Rng rng = {0, 0, 0};
-    v3 rpos = origin, rdir = V3(0, 0, 1);
-    v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0), pixel_color = V3(0, 0, 0);
-    HitInfo h;
-    h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
-    bool exhausted = false;                    // wave-uniform: the global pixel counter has run out
-    uint32_t chunk_next = 0, chunk_end = 0;    // wave-uniform: this wave's current chunk of pixel numbers
-
-    unsigned long long cyc_refill = 0, cyc_trace = 0, cyc_shade = 0, n_rounds = 0, lane_rounds = 0;  // STATS only, wave-uniform
-    for (;;) {
-        unsigned long long t0 = 0, t1 = 0, t2 = 0;
-        if (STATS) t0 = __builtin_amdgcn_s_memtime();
-        // ---- A. refill idle lanes --------------------------------------------------------------------
-        // The wave owns a chunk of consecutive pixel numbers (a few neighbouring tiles) and hands them to its idle
-        // lanes; when the chunk runs out it takes the next one from the global counter. Lanes of one wave therefore
-        // stay on at most two small image regions at any time, which keeps their rays and candidates similar.
-        {
-            bool need = st == PT_ST_IDLE;
-            unsigned long long m = __ballot(need);
-            // refill only once enough lanes are free, so that the newcomers share a tile
-            if ((uint32_t)__popcll(m) < fp.refill_min) m = 0ull;
-            while (m != 0ull && !exhausted) {
-                if (chunk_next == chunk_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&counters->next_pixel, fp.chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= total) {
-                        exhausted = true;
-                        break;
-                    }
-                    chunk_next = base;
-                    chunk_end = (total - base < fp.chunk) ? total : base + fp.chunk;
-                }
-                const uint32_t avail = chunk_end - chunk_next;
-                const uint32_t want = (uint32_t)__popcll(m);
-                const uint32_t take = want < avail ? want : avail;
-                const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
-                if (need && rank < take) {
-                    need = false;
-                    const uint32_t idx = chunk_next + rank;
-                    // tiles are visited in a scattered order (multiplication by a constant coprime to the tile count), so
-                    // that cheap and expensive image regions are spread over the whole launch instead of expensive ones
-                    // piling up at its end
-                    const uint32_t local_tile = (uint32_t)(((unsigned long long)(idx >> 6) * fp.tile_stride) % fp.n_local_tiles), within = idx & 63u;
-                    const uint32_t tile = local_tile * fp.part_count + fp.part_index;
-                    const uint32_t ty = tile / fp.tiles_x, tx = tile - ty * fp.tiles_x;
-                    const uint32_t px = tx * 8 + (within & 7u), py = ty * 8 + (within >> 3);
-                    if (px < fp.width && py < fp.height) {
-                        pix = py * fp.width + px;
-                        // fullscreen triangle at the pixel centre; src/raytrace.wgsl:210-217
-                        const float uvx = pt_div((float)px + 0.5f, W), uvy = pt_div((float)py + 0.5f, H);
-                        const float sx = (uvx * W) * tp1, sy = (uvy * H) * tp1;
-                        rng.x = pt_f2u(sx);
-                        rng.y = pt_f2u(sy);
-                        rng.z = rng.x ^ rng.y;
-                        const float dx = uvx * 2.0f - 1.0f;
-                        const float dy = (uvy * 2.0f - 1.0f) * -1.0f;
-                        v3 temp = V3(pt_fma(fp.vfc[4], dy, fp.vfc[0] * dx) + fp.vfc[8] + fp.vfc[12],
-                                     pt_fma(fp.vfc[5], dy, fp.vfc[1] * dx) + fp.vfc[9] + fp.vfc[13],
-                                     pt_fma(fp.vfc[6], dy, fp.vfc[2] * dx) + fp.vfc[10] + fp.vfc[14]);
-                        temp = normalize3(temp);
-                        const v3 dir0 = V3(pt_fma(fp.wfv[8], temp.z, pt_fma(fp.wfv[4], temp.y, fp.wfv[0] * temp.x)),
-                                           pt_fma(fp.wfv[9], temp.z, pt_fma(fp.wfv[5], temp.y, fp.wfv[1] * temp.x)),
-                                           pt_fma(fp.wfv[10], temp.z, pt_fma(fp.wfv[6], temp.y, fp.wfv[2] * temp.x)));
-                        slot[9 * 64] = dir0.x; slot[10 * 64] = dir0.y; slot[11 * 64] = dir0.z;
-                        sample = 0; bounce = 0; nrays = 0;
-                        pixel_color = V3(0, 0, 0);
-                        ray_color = V3(1, 1, 1);
-                        color = V3(0, 0, 0);
-                        rpos = origin;
-                        rdir = dir0;
-                        if (any_rays) {
-                            st = PT_ST_TRACE;
-                            primary_pending = true;
-                        } else {
-                            // no ray is ever traced: `samples` additions of zero, then the division (0/0 when samples == 0)
-                            out[pix] = make_float4(pt_div(0.0f, ns), pt_div(0.0f, ns), pt_div(0.0f, ns), 1.0f);
-                            aux_obj[pix] = PT_NONE; aux_flat[pix] = PT_NONE; aux_t[pix] = PT_T_MAX; aux_rays[pix] = 0u;
-                            need = true;  // this lane is free again at once
-                        }
-                    } else {
-                        need = true;      // pixel number outside the image (ragged edge tile)
-                    }
-                }
-                chunk_next += take;
-                m = __ballot(need);
-            }
-        }
-        if (!__any(st != PT_ST_IDLE)) {
-            if (exhausted) break;
-            continue;
-        }
-
-        // ---- B. trace --------------------------------------------------------------------------------
-        if (STATS) {
-            t1 = __builtin_amdgcn_s_memtime();
-            n_rounds++;
-            lane_rounds += (unsigned long long)__popcll(__ballot(st == PT_ST_TRACE));
-        }
-        {
-            const bool tracing = st == PT_ST_TRACE;
-            Best b;
-            closest_hit<TLAS, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
-            if (tracing) {
-                nrays++;
-                wave_rays++;
-                if (STATS && b.obj != PT_NONE) cnt.hits++;
-                h = finalize_hit(sc, rpos, rdir, b);
-                st = PT_ST_SHADE;
-                if (primary_pending) {
-                    primary_pending = false;
-                    slot[0] = __uint_as_float(h.obj);
-                    slot[1 * 64] = h.p.x; slot[2 * 64] = h.p.y; slot[3 * 64] = h.p.z;
-                    slot[4 * 64] = h.n.x; slot[5 * 64] = h.n.y; slot[6 * 64] = h.n.z;
-                    slot[7 * 64] = h.u; slot[8 * 64] = h.v;
-                    aux_obj[pix] = b.obj;
-                    aux_flat[pix] = (b.obj != PT_NONE) ? sc.objects[b.obj].tri_base + b.tri : PT_NONE;
-                    aux_t[pix] = b.t;
-                    // Pixels whose primary hit ends every path at once - a miss, or a surface whose albedo is black
-                    // (the emissive lights): no scatter, no RNG draw, every sample adds the same colour.
-                    bool terminal = false;
-                    v3 c = sky;
-                    if (h.obj != PT_NONE) {
-                        const DMaterial m = sc.materials[sc.objects[h.obj].mat];
-                        const v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
-                        if (dot3(alb, alb) < PT_EPSILON) {
-                            terminal = true;
-                            c = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
-                            if (m.emissive_texture != PT_NONE) c = sample_texture(sc, m.emissive_texture, h.u, h.v);
-                        }
-                    } else {
-                        terminal = true;
-                    }
-                    if (terminal) {
-                        c = V3(pt_fma(1.0f, c.x, 0.0f), pt_fma(1.0f, c.y, 0.0f), pt_fma(1.0f, c.z, 0.0f));
-                        for (uint32_t k = 0; k < samples; ++k) pixel_color = add3(pixel_color, c);
-                        out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
-                        aux_rays[pix] = samples;  // the reference traces the primary ray once per sample
-                        st = PT_ST_IDLE;
-                    }
-                }
-            }
-        }
-
-        // ---- C. shade (src/raytrace.wgsl:229-270) and advance (sample, bounce) -----------------------------
-        if (STATS) t2 = __builtin_amdgcn_s_memtime();
-        bool pending = st == PT_ST_SHADE;
-        while (__any(pending)) {
-            if (pending) {
-                bool end_path = false;
-                if (h.obj != PT_NONE) {
-                    const DMaterial m = sc.materials[sc.objects[h.obj].mat];
-                    v3 emissive = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
-                    if (m.emissive_texture != PT_NONE) emissive = sample_texture(sc, m.emissive_texture, h.u, h.v);
-                    color = V3(pt_fma(ray_color.x, emissive.x, color.x), pt_fma(ray_color.y, emissive.y, color.y),
-                               pt_fma(ray_color.z, emissive.z, color.z));
-                    const v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
-                    if (dot3(alb, alb) < PT_EPSILON) {
-                        end_path = true;
-                    } else {
-                        v3 N = h.n;
-                        if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
-                        v3 ndir, bcol;
-                        if (STATS) cnt.shades++;
-                        calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
-                        rdir = ndir;
-                        rpos = madd3(h.p, rdir, 0.001f);
-                        ray_color = mul3(ray_color, bcol);
-                        const float p = pt_max(ray_color.x, pt_max(ray_color.y, ray_color.z));
-                        bounce++;
-                        if (p < PT_EPSILON || bounce >= bounces) end_path = true;
-                    }
-                } else {
-                    color = V3(pt_fma(ray_color.x, sky.x, color.x), pt_fma(ray_color.y, sky.y, color.y),
-                               pt_fma(ray_color.z, sky.z, color.z));
-                    end_path = true;
-                }
-                if (end_path) {
-                    pixel_color = add3(pixel_color, color);
-                    sample++;
-                    if (sample >= samples) {
-                        out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
-                        // queries the reference would have run: it re-traces the primary ray for every sample
-                        aux_rays[pix] = nrays + samples - 1u;
-                        st = PT_ST_IDLE;
-                        pending = false;
-                    } else {
-                        bounce = 0;
-                        rpos = origin;
-                        rdir = V3(slot[9 * 64], slot[10 * 64], slot[11 * 64]);
-                        ray_color = V3(1, 1, 1);
-                        color = V3(0, 0, 0);
-                        h.obj = __float_as_uint(slot[0]);
-                        h.p = V3(slot[1 * 64], slot[2 * 64], slot[3 * 64]);
-                        h.n = V3(slot[4 * 64], slot[5 * 64], slot[6 * 64]);
-                        h.u = slot[7 * 64];
-                        h.v = slot[8 * 64];
-                    }
-                } else {
-                    st = PT_ST_TRACE;
-                    pending = false;
-                }
-            }
-        }
-        if (STATS) {
-            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            cyc_refill += t1 - t0;
-            cyc_trace += t2 - t1;
-            cyc_shade += t3 - t2;
-        }
-    }
-
-    uint32_t r = wave_sum_u32(wave_rays);
-    if (lane == 0) atomicAdd(&counters->rays, (unsigned long long)r);
-    if (STATS) {
-        uint32_t a = wave_sum_u32(cnt.xforms), b = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
-                 d = wave_sum_u32(cnt.shades), e = wave_sum_u32(cnt.hits);
-        if (lane == 0) {
-            atomicAdd(&counters->cyc_refill, cyc_refill);
-            atomicAdd(&counters->cyc_trace, cyc_trace);
-            atomicAdd(&counters->cyc_shade, cyc_shade);
-            atomicAdd(&counters->rounds, n_rounds);
-            atomicAdd(&counters->lane_rounds, lane_rounds);
-            atomicAdd(&counters->hits, (unsigned long long)e);
-            atomicAdd(&counters->xforms, (unsigned long long)a);
-            atomicAdd(&counters->box_tests, (unsigned long long)b);
-            atomicAdd(&counters->tri_tests, (unsigned long long)c);
-            atomicAdd(&counters->shades, (unsigned long long)d);
-        }
-    }
-}
-
-// ---- hit_all for a batch of rays (the query stage on its own) -----------------------
-struct DRay {
-    float pos[3];
-    float dir[3];
-};
-struct DHit {
-    uint32_t object, triangle, flat_id;
-    float t;
-    float p[3], n[3], uv[2];
-};
-
-template <bool TLAS>
-__global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_depth, const DRay* __restrict__ rays,
-                                               uint32_t n_rays, DHit* __restrict__ hits) {
-    PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    LdsStack stk;
-    stk.base = &s_stack[wave * stack_depth * 64 + lane];
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < n_rays;
-    v3 ro = V3(0, 0, 0), rd = V3(0, 0, 1);
-    if (valid) {
-        ro = V3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
-        rd = V3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
-    }
-    LaneCounters cnt = {0, 0, 0, 0, 0};
-    Best b;
-    closest_hit<TLAS, false>(sc, ro, rd, valid, b, stk, cnt);
-    if (!valid) return;
-    HitInfo h = finalize_hit(sc, ro, rd, b);
-    DHit o;
-    o.object = b.obj;
-    o.t = b.t;
-    if (b.obj != PT_NONE) {
-        o.triangle = b.tri;
-        o.flat_id = sc.objects[b.obj].tri_base + b.tri;
-    } else {
-        o.triangle = PT_NONE;
-        o.flat_id = PT_NONE;
-    }
-    o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
-    o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
-    o.uv[0] = h.u; o.uv[1] = h.v;
-    hits[i] = o;
-}
-
-// acc += frame; out = acc / n_frames  (radiance accumulation across frames; RGB only, A stays 1)
-__global__ void k_accumulate(float4* __restrict__ acc, float4* __restrict__ img, uint32_t n_pixels, float n_frames) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pixels) return;
-    float4 a = acc[i], f = img[i];
-    a.x += f.x; a.y += f.y; a.z += f.z; a.w = 1.0f;
-    acc[i] = a;
-    img[i] = make_float4(pt_div(a.x, n_frames), pt_div(a.y, n_frames), pt_div(a.z, n_frames), 1.0f);
 }
