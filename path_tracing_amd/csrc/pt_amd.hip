@@ -82,7 +82,7 @@ struct pt_ctx {
     bool stats_detail = false;
     bool timing_pending = false;
     PtStats stats{};
-    uint64_t last_paths = 0, last_primary = 0;
+    uint64_t last_paths = 0, last_primary = 0, last_primary_traced = 0;
 };
 
 namespace {
@@ -534,7 +534,7 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.primary_ms = ms_primary;
     ctx->stats.paths_ms = ms - ms_primary;
     ctx->stats.trace_launches = 2;
-    ctx->stats.rays = c.rays;
+    ctx->stats.rays = c.rays + ctx->last_primary_traced;
     ctx->stats.xforms = c.xforms;
     ctx->stats.box_tests = c.box_tests;
     ctx->stats.tri_tests = c.tri_tests;
@@ -549,10 +549,44 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.wave_life_max = c.wave_life_max;
     ctx->stats.waves = c.waves;
     ctx->stats.paths = ctx->last_paths;
-    ctx->stats.rays_reference = c.rays + ctx->last_primary;
+    ctx->stats.rays_reference = c.rays + ctx->last_primary_traced + ctx->last_primary;
     ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u);
     ctx->timing_pending = false;
     return PT_OK;
+}
+
+// Which closest-hit organisation the frame kernels use, and the LDS layout of the staged scene for PT_MODE_LDS:
+// scenes with at most 32 objects whose record arrays (object boxes, instances, meshes, triangles, attributes, BLAS
+// nodes, materials, texture descriptors) fit in kLdsSceneMaxBytes are copied into LDS by every workgroup.
+constexpr uint32_t kLdsSceneMaxBytes = 24 * 1024;
+int scene_mode(const pt_ctx* ctx, LdsScene* ls) {
+    std::memset(ls, 0, sizeof *ls);
+    if (ctx->use_tlas) return PT_MODE_TLAS;
+    if (ctx->n_objects == 0 || ctx->n_objects > 32 || ctx->cfg.accel == PT_ACCEL_BRUTE || std::getenv("PT_AMD_NO_LDS_SCENE")) return PT_MODE_LIST;
+    uint32_t off = 0;
+    auto place = [&](uint32_t bytes) { uint32_t o = off; off += (bytes + 15u) & ~15u; return o; };
+    ls->bytes_obj_box = 16u * ctx->n_objects;
+    ls->bytes_objects = (uint32_t)sizeof(DObject) * ctx->n_objects;
+    ls->bytes_meshes = (uint32_t)sizeof(DMesh) * ctx->n_meshes;
+    ls->bytes_tris = (uint32_t)sizeof(DTri) * ctx->n_tris;
+    ls->bytes_attrs = (uint32_t)sizeof(DTriAttr) * ctx->n_tris;
+    ls->bytes_blas = (uint32_t)sizeof(BvhNode) * ctx->n_blas_nodes;
+    ls->bytes_materials = (uint32_t)sizeof(DMaterial) * ctx->n_materials;
+    ls->bytes_textures = (uint32_t)sizeof(DTexture) * ctx->n_textures;
+    const uint64_t sum = 2ull * ls->bytes_obj_box + ls->bytes_objects + ls->bytes_meshes + ls->bytes_tris + ls->bytes_attrs +
+                         ls->bytes_blas + ls->bytes_materials + ls->bytes_textures;
+    if (sum > kLdsSceneMaxBytes) return PT_MODE_LIST;
+    ls->off_obj_lo = place(ls->bytes_obj_box);
+    ls->off_obj_hi = place(ls->bytes_obj_box);
+    ls->off_objects = place(ls->bytes_objects);
+    ls->off_meshes = place(ls->bytes_meshes);
+    ls->off_tris = place(ls->bytes_tris);
+    ls->off_attrs = place(ls->bytes_attrs);
+    ls->off_blas = place(ls->bytes_blas);
+    ls->off_materials = place(ls->bytes_materials);
+    ls->off_textures = place(ls->bytes_textures);
+    ls->total_bytes = off;
+    return PT_MODE_LDS;
 }
 
 // Enqueue one frame on `s`, image to device memory `out`.
@@ -614,17 +648,17 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
 
     PT_HIP(ctx, hipEventRecord(ctx->ev0, s));
     // 1. primary pass: one wave per tile
+    LdsScene ls;
+    const int mode = scene_mode(ctx, &ls);
     {
-        const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t);
+        const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
         const uint32_t grid = div_up(fp.n_local_tiles, 4);
+        using PrimaryFn = void (*)(PT_SCENE_PARAMS, LdsScene, FrameParams, uint32_t, float4*, uint32_t*, uint32_t*, float*, uint32_t*, PathRec*, DCounters*);
+        static const PrimaryFn table[3][2] = {{k_primary<PT_MODE_LIST, false>, k_primary<PT_MODE_LIST, true>},
+                                              {k_primary<PT_MODE_TLAS, false>, k_primary<PT_MODE_TLAS, true>},
+                                              {k_primary<PT_MODE_LDS, false>, k_primary<PT_MODE_LDS, true>}};
         if (grid) {
-            if (ctx->use_tlas) {
-                if (st) k_primary<true, true><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, o4, ao, af, at, ar, recs, dc);
-                else k_primary<true, false><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, o4, ao, af, at, ar, recs, dc);
-            } else {
-                if (st) k_primary<false, true><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, o4, ao, af, at, ar, recs, dc);
-                else k_primary<false, false><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), fp, depth, o4, ao, af, at, ar, recs, dc);
-            }
+            table[mode][st ? 1 : 0]<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, fp, depth, o4, ao, af, at, ar, recs, dc);
             PT_HIP(ctx, hipGetLastError());
         }
     }
@@ -640,16 +674,19 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         pp.chunk = ctx->chunk_pixels;
         // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
         pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
-        const size_t lds = (size_t)4 * (depth + PT_LANE_SLOTS) * 64 * sizeof(uint32_t);
-        using PathsFn = void (*)(PT_SCENE_PARAMS, PathParams, uint32_t, const PathRec*, float4*, uint32_t*, DCounters*);
-        PathsFn fn = ctx->use_tlas ? (st ? k_paths<true, true> : k_paths<true, false>) : (st ? k_paths<false, true> : k_paths<false, false>);
+        const size_t lds = (size_t)4 * (depth + PT_LANE_SLOTS) * 64 * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
+        using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, PathParams, uint32_t, const PathRec*, float4*, uint32_t*, DCounters*);
+        static const PathsFn ptable[3][2] = {{k_paths<PT_MODE_LIST, false>, k_paths<PT_MODE_LIST, true>},
+                                             {k_paths<PT_MODE_TLAS, false>, k_paths<PT_MODE_TLAS, true>},
+                                             {k_paths<PT_MODE_LDS, false>, k_paths<PT_MODE_LDS, true>}};
+        PathsFn fn = ptable[mode][st ? 1 : 0];
         int per_cu = 0;
         PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds));
         if (per_cu < 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: the path kernel does not fit on a compute unit with this traversal stack");
         if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
         const uint32_t grid = std::min(div_up(fp.n_local_tiles, 4), (uint32_t)per_cu * ctx->n_cus);
-        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u\n", per_cu, grid, lds, depth, pp.chunk, pp.refill_min);
-        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), pp, depth, recs, o4, ar, dc);
+        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u\n", mode, per_cu, grid, lds, depth, pp.chunk, pp.refill_min);
+        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, pp, depth, recs, o4, ar, dc);
         PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, s));
@@ -667,6 +704,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     }
     ctx->last_paths = local_pixels * fp.samples;
     ctx->last_primary = (fp.bounces > 0 && fp.samples > 0) ? local_pixels * (uint64_t)(fp.samples - 1) : 0;
+    ctx->last_primary_traced = (fp.bounces > 0 && fp.samples > 0) ? local_pixels : 0;  // one primary ray per pixel (k_primary)
 
     if (f->flags & (PT_FRAME_ACCUMULATE | PT_FRAME_RESET)) {
         if ((f->flags & PT_FRAME_RESET) || ctx->acc_w != f->width || ctx->acc_h != f->height) {
@@ -737,8 +775,8 @@ int pt_query(pt_ctx* ctx, const PtRay* rays_host, uint32_t n_rays, PtHit* hits_h
         SceneView sv = make_view(ctx);
         const uint32_t depth = stack_depth_needed(ctx);
         const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t);
-        if (ctx->use_tlas) k_query<true><<<div_up(n_rays, 256), 256, lds, s>>>(PT_SCENE_ARGS(sv), depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
-        else k_query<false><<<div_up(n_rays, 256), 256, lds, s>>>(PT_SCENE_ARGS(sv), depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        if (ctx->use_tlas) k_query<PT_MODE_TLAS><<<div_up(n_rays, 256), 256, lds, s>>>(PT_SCENE_ARGS(sv), depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        else k_query<PT_MODE_LIST><<<div_up(n_rays, 256), 256, lds, s>>>(PT_SCENE_ARGS(sv), depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
         PT_HIP(ctx, hipGetLastError());
         PT_HIP(ctx, hipMemcpyAsync(hits_host, ctx->d_hits.p, sizeof(PtHit) * (size_t)n_rays, hipMemcpyDeviceToHost, s));
         PT_HIP(ctx, hipStreamSynchronize(s));

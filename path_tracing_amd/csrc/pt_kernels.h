@@ -34,6 +34,44 @@ struct PathParams {
     uint32_t refill_min;  // a wave hands out new pixels only when at least this many of its lanes are idle (1..64)
 };
 
+// Where each scene array sits in the LDS copy (byte offsets from the start of the staged region, multiples of 16)
+// and how many bytes it has. Small scenes only: see lds_scene_layout() on the host side.
+struct LdsScene {
+    uint32_t off_obj_lo, off_obj_hi, off_objects, off_meshes, off_tris, off_attrs, off_blas, off_materials, off_textures;
+    uint32_t bytes_obj_box, bytes_objects, bytes_meshes, bytes_tris, bytes_attrs, bytes_blas, bytes_materials, bytes_textures;
+    uint32_t total_bytes;
+};
+
+PT_DEV void lds_copy16(uint32_t* dst_words, const void* src, uint32_t bytes) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst_words);
+    for (uint32_t i = threadIdx.x; i < bytes / 16u; i += blockDim.x) d4[i] = s4[i];
+}
+
+// Copy every scene record array into LDS and point the view at the copies. All later reads of objects, boxes, meshes,
+// triangles, BLAS nodes, materials and texture descriptors are then LDS reads (texels stay in global memory).
+PT_DEV void stage_scene_in_lds(SceneView& sc, const LdsScene& ls, uint32_t* lds) {
+    lds_copy16(lds + ls.off_obj_lo / 4, sc.obj_lo, ls.bytes_obj_box);
+    lds_copy16(lds + ls.off_obj_hi / 4, sc.obj_hi, ls.bytes_obj_box);
+    lds_copy16(lds + ls.off_objects / 4, sc.objects, ls.bytes_objects);
+    lds_copy16(lds + ls.off_meshes / 4, sc.meshes, ls.bytes_meshes);
+    lds_copy16(lds + ls.off_tris / 4, sc.tris, ls.bytes_tris);
+    lds_copy16(lds + ls.off_attrs / 4, sc.tri_attrs, ls.bytes_attrs);
+    lds_copy16(lds + ls.off_blas / 4, sc.blas_nodes, ls.bytes_blas);
+    lds_copy16(lds + ls.off_materials / 4, sc.materials, ls.bytes_materials);
+    lds_copy16(lds + ls.off_textures / 4, sc.textures, ls.bytes_textures);
+    __syncthreads();
+    sc.obj_lo = reinterpret_cast<const float4*>(lds + ls.off_obj_lo / 4);
+    sc.obj_hi = reinterpret_cast<const float4*>(lds + ls.off_obj_hi / 4);
+    sc.objects = reinterpret_cast<const DObject*>(lds + ls.off_objects / 4);
+    sc.meshes = reinterpret_cast<const DMesh*>(lds + ls.off_meshes / 4);
+    sc.tris = reinterpret_cast<const DTri*>(lds + ls.off_tris / 4);
+    sc.tri_attrs = reinterpret_cast<const DTriAttr*>(lds + ls.off_attrs / 4);
+    sc.blas_nodes = reinterpret_cast<const BvhNode*>(lds + ls.off_blas / 4);
+    sc.materials = reinterpret_cast<const DMaterial*>(lds + ls.off_materials / 4);
+    sc.textures = reinterpret_cast<const DTexture*>(lds + ls.off_textures / 4);
+}
+
 PT_DEV uint32_t wave_sum_u32(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
@@ -55,23 +93,24 @@ PT_DEV bool primary_is_terminal(const SceneView& sc, const HitInfo& h, v3 sky, v
 }
 
 // ---- primary pass: one wave per 8x8 pixel tile, four tiles per workgroup --------------------------------------
-template <bool TLAS, bool STATS>
-__global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, FrameParams fp, uint32_t stack_depth, float4* __restrict__ out,
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, FrameParams fp, uint32_t stack_depth, float4* __restrict__ out,
                                                  uint32_t* __restrict__ aux_obj, uint32_t* __restrict__ aux_flat,
                                                  float* __restrict__ aux_t, uint32_t* __restrict__ aux_rays,
                                                  PathRec* __restrict__ recs, DCounters* __restrict__ counters) {
     PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes]
+    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes], then the staged scene (PT_MODE_LDS)
+    if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + 4 * stack_depth * 64);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t local_tile = blockIdx.x * 4 + wave;
-    if (local_tile >= fp.n_local_tiles) return;  // wave-uniform
+    const bool tile_ok = local_tile < fp.n_local_tiles;  // wave-uniform; the wave stays for the block-wide append below
     LdsStack stk;
     stk.base = &s_mem[wave * stack_depth * 64 + lane];
 
     const uint32_t tile = local_tile * fp.part_count + fp.part_index;
     const uint32_t ty = tile / fp.tiles_x, tx = tile - ty * fp.tiles_x;
     const uint32_t px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-    const bool valid = px < fp.width && py < fp.height;
+    const bool valid = tile_ok && px < fp.width && py < fp.height;
     const uint32_t pix = py * fp.width + px;
 
     // fullscreen triangle at the pixel centre; src/raytrace.wgsl:210-217
@@ -104,7 +143,7 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, FrameParams fp
 
     LaneCounters cnt = {0, 0, 0, 0, 0};
     Best b;
-    closest_hit<TLAS, STATS>(sc, origin, dir0, valid, b, stk, cnt);
+    closest_hit<MODE, STATS>(sc, origin, dir0, valid, b, stk, cnt);
     bool to_list = false;
     HitInfo h;
     h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
@@ -124,12 +163,20 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, FrameParams fp
             to_list = true;
         }
     }
-    // append this tile's surviving pixels to the path list: one atomic per wave
+    // append the workgroup's surviving pixels to the path list: one atomic per workgroup (a single counter takes
+    // only ~90 atomics per microsecond, so one per wave would cost more than the tracing)
+    __shared__ uint32_t s_count[4], s_base;
     const unsigned long long m = __ballot(to_list);
-    if (m != 0ull) {
-        uint32_t base = 0;
-        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&counters->n_paths, (uint32_t)__popcll(m));
-        base = __shfl(base, __builtin_ctzll(m), 64);
+    if (lane == 0) s_count[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+        s_base = n ? atomicAdd(&counters->n_paths, n) : 0u;
+    }
+    __syncthreads();
+    {
+        uint32_t base = s_base;
+        for (uint32_t w = 0; w < wave; ++w) base += s_count[w];
         if (to_list) {
             PathRec r;
             r.a = make_float4(__uint_as_float(pix), __uint_as_float(h.obj), h.u, h.v);
@@ -139,8 +186,7 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, FrameParams fp
             recs[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
         }
     }
-    const uint32_t r = wave_sum_u32(valid ? 1u : 0u);
-    if (lane == 0) atomicAdd(&counters->rays, (unsigned long long)r);
+    // (the primary rays, one per pixel of the partition, are added to the ray count on the host)
     if (STATS) {
         const uint32_t a = wave_sum_u32(cnt.xforms), bb = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
                        e = wave_sum_u32(cnt.hits);
@@ -167,12 +213,13 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, FrameParams fp
 #define PT_ST_TRACE 2u
 #define PT_LANE_SLOTS 12  // per-lane LDS words: primary hit record (9) + primary direction (3)
 
-template <bool TLAS, bool STATS>
-__global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, PathParams pp, uint32_t stack_depth,
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, PathParams pp, uint32_t stack_depth,
                                                                     const PathRec* __restrict__ recs, float4* __restrict__ out,
                                                                     uint32_t* __restrict__ aux_rays, DCounters* __restrict__ counters) {
     PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes] stacks, then [4 waves][PT_LANE_SLOTS][64 lanes]
+    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes] stacks, [4 waves][PT_LANE_SLOTS][64 lanes], staged scene
+    if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + 4 * (stack_depth + PT_LANE_SLOTS) * 64);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;
     stk.base = &s_mem[wave * stack_depth * 64 + lane];
@@ -327,7 +374,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
         if (__any(st == PT_ST_TRACE)) {
             const bool tracing = st == PT_ST_TRACE;
             Best b;
-            closest_hit<TLAS, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
+            closest_hit<MODE, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
             if (tracing) {
                 nrays++;
                 lane_rays++;
@@ -379,7 +426,7 @@ struct DHit {
     float p[3], n[3], uv[2];
 };
 
-template <bool TLAS>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_depth, const DRay* __restrict__ rays,
                                                uint32_t n_rays, DHit* __restrict__ hits) {
     PT_SCENE_VIEW_FROM_PARAMS()
@@ -396,7 +443,7 @@ __global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_d
     }
     LaneCounters cnt = {0, 0, 0, 0, 0};
     Best b;
-    closest_hit<TLAS, false>(sc, ro, rd, valid, b, stk, cnt);
+    closest_hit<MODE, false>(sc, ro, rd, valid, b, stk, cnt);
     if (!valid) return;
     HitInfo h = finalize_hit(sc, ro, rd, b);
     DHit o;

@@ -166,7 +166,7 @@ PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t root, const Sla
 // The reference gates the whole mesh on hit_box() BEFORE looking at triangles; the gate only ever rejects, so it
 // is evaluated afterwards and only for objects that produced a winning candidate (the exact arithmetic with its
 // three divisions is then needed once per accepted object instead of once per visited object).
-template <bool STATS>
+template <bool STATS, bool PERLANE>
 PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& best, LdsStack stk, int sp0,
                         LaneCounters& cnt) {
     const DObject* ob = &sc.objects[obj];
@@ -177,6 +177,30 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
     if (STATS) cnt.xforms++;
     Best cand = best;
     bool changed = false;
+    if (PERLANE) {
+        // scene records live in LDS: every lane reads its own mesh and triangles, no grouping by mesh needed
+        const DMesh* me = &sc.meshes[mesh_id];
+        const uint32_t root = me->blas_root, tri_first = me->tri_first;
+        if (root == PT_NONE) {
+            const uint32_t n = me->tri_count;
+            for (uint32_t i = 0; i < n; ++i) {
+                const DTri* T = &sc.tris[tri_first + i];
+                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
+            }
+        } else {
+            const float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) + me->max_abs);
+            const SlabRay sr = make_slab_ray(lo, ld, pad);
+            bvh_walk<STATS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+                const DTri* T = &sc.tris[tri_first + tri];
+                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
+            });
+        }
+        if (changed) {
+            const float t_aabb = hit_box_exact(me->bmin, me->bmax, lo, ld);   // reference :77-80
+            if (!(t_aabb < PT_T_MIN)) best = cand;
+        }
+        return;
+    }
     bool pending = true;
     while (__any(pending)) {
         if (pending) {
@@ -221,7 +245,7 @@ PT_DEV SlabRay world_slab_ray(v3 ro, v3 rd) {
 // each lane collects its own candidates in a bit mask and then works through them.
 // An object whose world box the ray misses cannot contain an accepted triangle, so skipping it changes nothing.
 // With sc.cull_boxes == 0 (PT_ACCEL_BRUTE) every object is a candidate: the reference's exhaustive loop.
-template <bool STATS>
+template <bool STATS, bool PERLANE>
 PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
     const SlabRay sr = world_slab_ray(ro, rd);
     const uint32_t n = sc.n_objects;
@@ -245,7 +269,7 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
                 const uint32_t o = base + (uint32_t)__builtin_ctz(mask);
                 mask &= mask - 1;
                 float tn;
-                if (!cull || slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn)) object_test<STATS>(sc, o, ro, rd, best, stk, 0, cnt);
+                if (!cull || slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn)) object_test<STATS, PERLANE>(sc, o, ro, rd, best, stk, 0, cnt);
             }
         }
     }
@@ -257,18 +281,22 @@ PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
     if (sc.tlas_root == PT_NONE) return;
     const SlabRay sr = world_slab_ray(ro, rd);
     bvh_walk<STATS>(sc.tlas_nodes, sc.tlas_root, sr, best.t, stk, 0, active, cnt,
-                    [&](uint32_t obj, int sp) { object_test<STATS>(sc, obj, ro, rd, best, stk, sp, cnt); });
+                    [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, ro, rd, best, stk, sp, cnt); });
 }
 
-template <bool TLAS, bool STATS>
+// MODE: how hit_all finds its candidates.
+#define PT_MODE_LIST 0  // object list culled with world boxes, scene records in global memory
+#define PT_MODE_TLAS 1  // TLAS walk
+#define PT_MODE_LDS 2   // object list, every scene record staged in LDS (small scenes)
+template <int MODE, bool STATS>
 PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
     best.t = PT_T_MAX;
     best.obj = PT_NONE;
     best.tri = PT_NONE;
     best.u = 0.0f;
     best.v = 0.0f;
-    if (TLAS) closest_hit_tlas<STATS>(sc, ro, rd, active, best, stk, cnt);
-    else closest_hit_list<STATS>(sc, ro, rd, active, best, stk, cnt);
+    if (MODE == PT_MODE_TLAS) closest_hit_tlas<STATS>(sc, ro, rd, active, best, stk, cnt);
+    else closest_hit_list<STATS, MODE == PT_MODE_LDS>(sc, ro, rd, active, best, stk, cnt);
 }
 
 // The hit_record of the winner (reference src/query.wgsl:113-120), evaluated once per ray.
