@@ -270,6 +270,7 @@ typedef struct PtStats {
      * closest hit, and in shading; rounds of the wave loop; lanes tracing per round */
     uint64_t cycles_refill, cycles_trace, cycles_shade, wave_rounds, lane_rounds;
     uint64_t wave_life_sum, wave_life_max, waves; /* lifetime of the path kernel's waves, shader cycles */
+    uint32_t wave_life_hist[32];                  /* ... histogram, 2^19 cycles per bucket              */
 } PtStats;
 
 /* detail != 0 re-runs nothing; it only selects whether the next renders also

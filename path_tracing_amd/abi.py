@@ -82,10 +82,11 @@ class PtStats(C.Structure):
                 ("trace_launches", C.c_uint32), ("accel_used", C.c_uint32),
                 ("cycles_refill", C.c_uint64), ("cycles_trace", C.c_uint64), ("cycles_shade", C.c_uint64),
                 ("wave_rounds", C.c_uint64), ("lane_rounds", C.c_uint64),
-                ("wave_life_sum", C.c_uint64), ("wave_life_max", C.c_uint64), ("waves", C.c_uint64)]
+                ("wave_life_sum", C.c_uint64), ("wave_life_max", C.c_uint64), ("waves", C.c_uint64),
+                ("wave_life_hist", C.c_uint32 * 32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n == "wave_life_hist" else getattr(self, n)) for n, _ in self._fields_}
 
 
 assert C.sizeof(PtSettings) == 32 and C.sizeof(PtFrame) == 192 and C.sizeof(PtConfig) == 32

@@ -21,7 +21,7 @@ static_assert(sizeof(DRay) == sizeof(PtRay) && sizeof(DHit) == sizeof(PtHit), "q
 
 namespace {
 
-constexpr uint32_t kBlasMinTris = 8;    // PT_ACCEL_AUTO: meshes with more triangles than this get a BLAS
+constexpr uint32_t kBlasMinTris = 16;   // PT_ACCEL_AUTO: meshes with more triangles than this get a BLAS
 constexpr uint32_t kTlasMinObjects = 12; // PT_ACCEL_AUTO: scenes with more objects than this get a TLAS
 constexpr uint32_t kMaxStackDepth = 96;  // LDS: 4 waves * depth * 256 B per workgroup
 
@@ -548,6 +548,7 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.wave_life_sum = c.wave_life_sum;
     ctx->stats.wave_life_max = c.wave_life_max;
     ctx->stats.waves = c.waves;
+    for (int k = 0; k < 32; ++k) ctx->stats.wave_life_hist[k] = c.life_hist[k];
     ctx->stats.paths = ctx->last_paths;
     ctx->stats.rays_reference = c.rays + ctx->last_primary_traced + ctx->last_primary;
     ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u);

@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             const unsigned long long life = __builtin_amdgcn_s_memtime() - t_begin;
             atomicAdd(&counters->wave_life_sum, life);
             atomicMax(&counters->wave_life_max, life);
+            { unsigned long long bkt = life >> 19; if (bkt > 31) bkt = 31; atomicAdd(&counters->life_hist[bkt], 1u); }
             if (n_rounds) atomicAdd(&counters->waves, 1ull);
             atomicAdd(&counters->cyc_refill, cyc_refill);
             atomicAdd(&counters->cyc_trace, cyc_trace);

@@ -149,4 +149,5 @@ struct DCounters {
     unsigned long long _pad[1];
     // phase clocks of the frame kernel (shader cycles summed over waves), STATS variant only
     unsigned long long cyc_refill, cyc_trace, cyc_shade, rounds, lane_rounds, wave_life_sum, wave_life_max, waves;
+    unsigned int life_hist[32];   // histogram of k_paths wave lifetimes, 2^19 cycles per bucket (STATS only)
 };

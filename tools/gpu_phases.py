@@ -13,6 +13,7 @@ for n in (sys.argv[1:] or list(SCENES)):
         ctx.set_stats_detail(True)
         ctx.render(scene.frame()); ctx.render(scene.frame())
         s = ctx.stats()
+    print("   life histogram (0.5M-cycle buckets):", s["wave_life_hist"])
     tot = s["cycles_refill"] + s["cycles_trace"] + s["cycles_shade"]
     print(f"{n}: ms {s['trace_ms']:.3f} rays {s['rays']} rounds {s['wave_rounds']} lanes/round {s['lane_rounds'] / max(s['wave_rounds'], 1):.1f} "
           f"refill {100 * s['cycles_refill'] / tot:.1f}% trace {100 * s['cycles_trace'] / tot:.1f}% shade {100 * s['cycles_shade'] / tot:.1f}% "
