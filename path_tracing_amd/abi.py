@@ -94,7 +94,7 @@ assert C.sizeof(PtSettings) == 32 and C.sizeof(PtFrame) == 192 and C.sizeof(PtCo
 # every symbol include/pt_amd.h declares
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_upload_materials",
            "pt_upload_objects", "pt_render", "pt_render_device", "pt_query", "pt_read_aux",
-           "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel"]
+           "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log"]
 
 LIB_NAME = "libpt_amd.so"
 
@@ -135,6 +135,7 @@ def load_library():
     lib.pt_get_stats.argtypes = [vp, C.POINTER(PtStats)]
     lib.pt_device_info.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.pt_debug_check_accel.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.pt_debug_wave_log.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32)]
     for name in EXPORTS:
         if name != "pt_last_error":
             getattr(lib, name).restype = C.c_int
@@ -265,6 +266,15 @@ class Context:
         st = PtStats()
         self._check(self._lib.pt_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def wave_log(self) -> np.ndarray:
+        """Per-wave records (n, 8) u32 of the last frame rendered with detailed statistics."""
+        n = C.c_uint32(0)
+        self._check(self._lib.pt_debug_wave_log(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 8), dtype=np.uint32)
+        if n.value:
+            self._check(self._lib.pt_debug_wave_log(self._h, _ptr(out), out.nbytes, C.byref(n)))
+        return out
 
     def check_accel(self) -> dict:
         e, t, b = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)

@@ -62,7 +62,7 @@ struct pt_ctx {
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors;
     // frame outputs
-    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths;
+    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_sweeps_done, d_carry, d_wave_log;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
@@ -77,6 +77,8 @@ struct pt_ctx {
     uint32_t n_cus = 256;
     uint32_t chunk_pixels = 64;   // see PathParams::chunk
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
+    uint32_t wave_log_records = 0;
+    uint32_t max_sweeps = 5;      // see PathParams::n_sweeps
     uint32_t aux_w = 0, aux_h = 0;
     uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
     bool stats_detail = false;
@@ -129,9 +131,9 @@ int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t
     k_morton<<<div_up(n, 256), 256, 0, s>>>(box_lo, box_hi, first, n, bounds, k0, v0);
     uint32_t* hist = ctx->t_hist.as<uint32_t>();
     for (uint32_t shift = 0; shift < 32; shift += 8) {
-        k_rs_hist<<<n_blocks, 64, 0, s>>>(k0, n, shift, n_blocks, hist);
+        k_rs_hist<8><<<n_blocks, 64, 0, s>>>(k0, n, nullptr, shift, n_blocks, hist);
         k_rs_scan<<<1, 1024, 0, s>>>(hist, 256 * n_blocks);
-        k_rs_scatter<<<n_blocks, 64, 0, s>>>(k0, v0, k1, v1, n, shift, n_blocks, hist);
+        k_rs_scatter<8><<<n_blocks, 64, 0, s>>>(k0, v0, k1, v1, n, nullptr, shift, n_blocks, hist);
         std::swap(k0, k1);
         std::swap(v0, v1);
     }
@@ -173,6 +175,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         ctx->device = cfg->device;
         ctx->n_cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
         if (const char* e = std::getenv("PT_AMD_REFILL_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_min = (uint32_t)v; }
+        if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; }
         std::snprintf(ctx->info, sizeof ctx->info, "pt_amd abi %d | %s %s | %d CUs | %d MHz | %.0f GiB", PT_ABI_VERSION, prop.name,
                       prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1073741824.0);
@@ -208,7 +211,7 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
-                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths};
+                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_wave_log};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -676,7 +679,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
         pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
         const size_t lds = (size_t)4 * (depth + PT_LANE_SLOTS) * 64 * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
-        using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, PathParams, uint32_t, const PathRec*, float4*, uint32_t*, DCounters*);
+        using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, PathParams, uint32_t, const PathRec*, PathCarry*, uint32_t*, float4*, uint32_t*, DCounters*, uint4*);
         static const PathsFn ptable[3][2] = {{k_paths<PT_MODE_LIST, false>, k_paths<PT_MODE_LIST, true>},
                                              {k_paths<PT_MODE_TLAS, false>, k_paths<PT_MODE_TLAS, true>},
                                              {k_paths<PT_MODE_LDS, false>, k_paths<PT_MODE_LDS, true>}};
@@ -686,8 +689,37 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         if (per_cu < 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: the path kernel does not fit on a compute unit with this traversal stack");
         if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
         const uint32_t grid = std::min(div_up(fp.n_local_tiles, 4), (uint32_t)per_cu * ctx->n_cus);
-        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u\n", mode, per_cu, grid, lds, depth, pp.chunk, pp.refill_min);
-        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, pp, depth, recs, o4, ar, dc);
+        // Sample slices ("sweeps"): half of the samples, then a quarter, ... so that the items handed out last are
+        // short. Only with whole-chunk refill (a wave then owns one chunk at a time and can report it complete).
+        pp.n_sweeps = 1;
+        pp.sweep_end[0] = fp.samples;
+        if (pp.refill_min == 64u && pp.chunk == 64u && fp.samples >= 16u && ctx->max_sweeps > 1u) {
+            uint32_t n = 0, done = 0, left = fp.samples;
+            while (n + 1u < ctx->max_sweeps && left >= 8u) {
+                const uint32_t len = left / 2u;
+                done += len;
+                left -= len;
+                pp.sweep_end[n++] = done;
+            }
+            pp.sweep_end[n++] = fp.samples;
+            pp.n_sweeps = n;
+        }
+        if (pp.n_sweeps > 1u) {
+            const size_t bytes = sizeof(uint32_t) * (size_t)fp.n_local_tiles;   // one flag per chunk of 64 entries
+            PT_HIP(ctx, ctx->d_sweeps_done.ensure(bytes));
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_sweeps_done.p, 0, bytes, s));
+            PT_HIP(ctx, ctx->d_carry.ensure(sizeof(PathCarry) * (size_t)fp.n_local_tiles * 64));
+        }
+        uint4* wlog = nullptr;
+        ctx->wave_log_records = 0;
+        if (st) {
+            PT_HIP(ctx, ctx->d_wave_log.ensure((size_t)32 * grid * 4));
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_log.p, 0, (size_t)32 * grid * 4, s));
+            wlog = ctx->d_wave_log.as<uint4>();
+            ctx->wave_log_records = grid * 4u;
+        }
+        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u sweeps=%u\n", mode, per_cu, grid, lds, depth, pp.chunk, pp.refill_min, pp.n_sweeps);
+        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, pp, depth, recs, ctx->d_carry.as<PathCarry>(), ctx->d_sweeps_done.as<uint32_t>(), o4, ar, dc, wlog);
         PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, s));
@@ -809,6 +841,22 @@ int pt_read_aux(pt_ctx* ctx, uint32_t kind, void* out_host, size_t out_bytes) {
         return PT_OK;
     } catch (...) {
         return fail(ctx, PT_ERR_DEVICE, "pt_read_aux: unexpected exception");
+    }
+}
+
+int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n_records) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!n_records) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_debug_wave_log: null argument");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        int rc = finish_timing(ctx);
+        if (rc != PT_OK) return rc;
+        *n_records = ctx->wave_log_records;
+        const size_t bytes = std::min(out_bytes, (size_t)32 * ctx->wave_log_records);
+        if (out_host && bytes) PT_HIP(ctx, hipMemcpy(out_host, ctx->d_wave_log.p, bytes, hipMemcpyDeviceToHost));
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_debug_wave_log: unexpected exception");
     }
 }
 

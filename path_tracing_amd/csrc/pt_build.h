@@ -195,21 +195,23 @@ __global__ void k_morton(const float4* __restrict__ box_lo, const float4* __rest
 #define RS_ITEMS 16
 #define RS_KEYS (64 * RS_ITEMS)
 
-__global__ __launch_bounds__(64) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
-                                                uint32_t n_blocks, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t cnt[256];
-    for (int d = threadIdx.x; d < 256; d += 64) cnt[d] = 0;
+template <int BITS = 8>
+__global__ __launch_bounds__(64) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_ptr,
+                                                uint32_t shift, uint32_t n_blocks, uint32_t* __restrict__ hist) {
+    constexpr int DIGITS = 1 << BITS;
+    __shared__ uint32_t cnt[DIGITS];
+    if (n_ptr) n = *n_ptr;  // key count produced on the device (the grid is sized for the largest possible count)
+    for (int d = threadIdx.x; d < DIGITS; d += 64) cnt[d] = 0;
     __syncthreads();
     uint32_t base = blockIdx.x * RS_KEYS;
     for (int j = 0; j < RS_ITEMS; ++j) {
         uint32_t i = base + j * 64 + threadIdx.x;
-        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & (DIGITS - 1u)], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < 256; d += 64) hist[d * n_blocks + blockIdx.x] = cnt[d];
+    for (int d = threadIdx.x; d < DIGITS; d += 64) hist[d * n_blocks + blockIdx.x] = cnt[d];
 }
 
-// exclusive scan of `total` counters in place, one workgroup of 1024 threads
 __global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* __restrict__ hist, uint32_t total) {
     __shared__ uint32_t part[1024];
     uint32_t per = (total + 1023u) / 1024u;
@@ -232,11 +234,15 @@ __global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* __restrict__ hist, u
     }
 }
 
+template <int BITS = 8>
 __global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
-                                                   uint32_t shift, uint32_t n_blocks, const uint32_t* __restrict__ hist) {
-    __shared__ uint32_t offs[256];
-    for (int d = threadIdx.x; d < 256; d += 64) offs[d] = hist[d * n_blocks + blockIdx.x];
+                                                   const uint32_t* __restrict__ n_ptr, uint32_t shift, uint32_t n_blocks,
+                                                   const uint32_t* __restrict__ hist) {
+    constexpr int DIGITS = 1 << BITS;
+    __shared__ uint32_t offs[DIGITS];
+    if (n_ptr) n = *n_ptr;
+    for (int d = threadIdx.x; d < DIGITS; d += 64) offs[d] = hist[d * n_blocks + blockIdx.x];
     __syncthreads();
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -245,10 +251,10 @@ __global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t* __restrict__ 
         uint32_t i = base + j * 64 + lane;
         bool ok = i < n;
         uint32_t key = ok ? keys_in[i] : 0u;
-        uint32_t val = ok ? vals_in[i] : 0u;
-        uint32_t digit = (key >> shift) & 255u;
+        uint32_t val = ok ? (vals_in ? vals_in[i] : i) : 0u;   // no value array: the values are the positions
+        uint32_t digit = (key >> shift) & (DIGITS - 1u);
         unsigned long long peers = __ballot(ok);
-        for (int bit = 0; bit < 8; ++bit) {
+        for (int bit = 0; bit < BITS; ++bit) {
             unsigned long long bmask = __ballot((digit >> bit) & 1u);
             peers &= ((digit >> bit) & 1u) ? bmask : ~bmask;
         }
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t* __restrict__ 
         if (ok && rank == 0) offs[digit] += __popcll(peers);
         __syncthreads();
         if (ok) {
-            keys_out[pos] = key;
+            if (keys_out) keys_out[pos] = key;
             vals_out[pos] = val;
         }
     }

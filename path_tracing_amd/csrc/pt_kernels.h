@@ -7,6 +7,11 @@
 //              here; every other pixel is appended, with its hit record, to the path list.
 //   k_paths    persistent waves over the path list: the sample x bounce loop of src/raytrace.wgsl:221-273 with the
 //              reference's per-pixel order of RNG draws and f32 accumulations, one pixel per lane at a time.
+//              The work queue holds (sweep, chunk) items, sweep-major: a chunk is 64 consecutive list entries, a
+//              sweep is a slice of the samples (half of them, then a quarter, ...). A pixel's state (RNG, radiance
+//              sum, ray count) is parked in its list entry between sweeps; the order of operations per pixel is
+//              unchanged. The slices get shorter towards the end of the launch, so the waves run out of work within
+//              one short slice of each other instead of one whole pixel.
 //   k_query    hit_all for a batch of rays (tests, tools).
 //   k_accumulate  running mean over frames.
 #pragma once
@@ -17,7 +22,7 @@
 #define PT_PATHS_MIN_WAVES 4   // waves per SIMD k_paths is compiled for (caps its VGPR allocation)
 #endif
 
-// One entry of the path list: everything k_paths needs to run a pixel. 64 B.
+// One entry of the path list: what k_primary found for a pixel that needs paths. 64 B, constant during k_paths.
 struct PathRec {
     float4 a;  // bits(pix), bits(object of the primary hit), hit uv.x, hit uv.y
     float4 b;  // hit p.xyz, hit n.x
@@ -26,13 +31,26 @@ struct PathRec {
 };
 static_assert(sizeof(PathRec) == 64, "PathRec");
 
+// State of a pixel parked between two sweeps, one per list entry: rng x y z, rays so far, radiance sum x y z, 0.
+// Written by one workgroup and read by another (possibly on another XCD, whose L2 is not coherent with the
+// writer's) inside one launch, so it only moves through device-scope atomic loads and stores, which bypass the
+// non-coherent cache levels; the chunk's flag is published after the stores have been acknowledged.
+struct PathCarry {
+    uint32_t w[8];
+};
+PT_DEV void carry_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PT_DEV uint32_t carry_load(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct PathParams {
     float origin[3];
     float sky[3];
     uint32_t bounces, samples;
     uint32_t chunk;       // path numbers a wave takes from the work counter at a time (multiple of 64)
     uint32_t refill_min;  // a wave hands out new pixels only when at least this many of its lanes are idle (1..64)
+    uint32_t n_sweeps;      // the samples of a pixel are run in this many consecutive slices (1..PT_MAX_SWEEPS)
+    uint32_t sweep_end[8];  // slice j runs samples [sweep_end[j-1], sweep_end[j]); sweep_end[n_sweeps-1] == samples
 };
+#define PT_MAX_SWEEPS 8
 
 // Where each scene array sits in the LDS copy (byte offsets from the start of the staged region, multiples of 16)
 // and how many bytes it has. Small scenes only: see lds_scene_layout() on the host side.
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, F
         return;
     }
 
-    LaneCounters cnt = {0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
     Best b;
     closest_hit<MODE, STATS>(sc, origin, dir0, valid, b, stk, cnt);
     bool to_list = false;
@@ -211,12 +229,17 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, F
 #define PT_ST_IDLE 0u
 #define PT_ST_SHADE 1u
 #define PT_ST_TRACE 2u
+#ifndef PT_WAVE_PRIO_PASSES
+#define PT_WAVE_PRIO_PASSES 2u  // object-test passes in a round from which a wave raises its issue priority
+#endif
 #define PT_LANE_SLOTS 12  // per-lane LDS words: primary hit record (9) + primary direction (3)
 
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, PathParams pp, uint32_t stack_depth,
-                                                                    const PathRec* __restrict__ recs, float4* __restrict__ out,
-                                                                    uint32_t* __restrict__ aux_rays, DCounters* __restrict__ counters) {
+                                                                    const PathRec* __restrict__ recs, PathCarry* __restrict__ carry,
+                                                                    uint32_t* __restrict__ sweeps_done,
+                                                                    float4* __restrict__ out, uint32_t* __restrict__ aux_rays,
+                                                                    DCounters* __restrict__ counters, uint4* __restrict__ wave_log) {
     PT_SCENE_VIEW_FROM_PARAMS()
     extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes] stacks, [4 waves][PT_LANE_SLOTS][64 lanes], staged scene
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + 4 * (stack_depth + PT_LANE_SLOTS) * 64);
@@ -232,19 +255,30 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     const uint32_t bounces = pp.bounces, samples = pp.samples;
     const float ns = (float)samples;
 
-    LaneCounters cnt = {0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
     uint32_t lane_rays = 0;
     unsigned long long t_begin = 0;
-    if (STATS) t_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long t_begin_real = 0;
+    if (STATS) {
+        t_begin = __builtin_amdgcn_s_memtime();
+        t_begin_real = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz, the same on every XCD
+    }
 
-    uint32_t st = PT_ST_IDLE, pix = 0, sample = 0, bounce = 0, nrays = 0;
+    uint32_t st = PT_ST_IDLE, pix = 0, sample = 0, bounce = 0, nrays = 0, entry = 0;
     Rng rng = {0, 0, 0};
     v3 rpos = origin, rdir = V3(0, 0, 1);
     v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0), pixel_color = V3(0, 0, 0);
     HitInfo h;
     h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
-    bool exhausted = false;                  // wave-uniform: the global counter has run out
-    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: this wave's current chunk of list entries
+    // wave-uniform scheduling state
+    bool exhausted = false;                  // the work queue has run out
+    uint32_t chunk_next = 0, chunk_end = 0;  // list entries of the current item not handed to lanes yet
+    uint32_t item = PT_NONE;                 // queue item taken but not started: the chunk's previous sweep is still running elsewhere
+    uint32_t cur_chunk = PT_NONE;            // chunk whose sweep this wave has to report as complete (n_sweeps > 1)
+    uint32_t sw_index = 0, sw_begin = 0, sw_end = samples;
+    const uint32_t n_chunks_total = (total + pp.chunk - 1u) / pp.chunk;
+    const uint32_t n_items = n_chunks_total * pp.n_sweeps;
+    uint32_t first_entry = 0xFFFFFFFFu, n_chunks = 0;  // STATS only
     unsigned long long cyc_refill = 0, cyc_trace = 0, cyc_shade = 0, n_rounds = 0, lane_rounds = 0;  // STATS only
 
     for (;;) {
@@ -254,18 +288,41 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
         {
             bool need = st == PT_ST_IDLE;
             unsigned long long m = __ballot(need);
+            if (cur_chunk != PT_NONE && chunk_next == chunk_end && m == ~0ull) {
+                // every pixel of the chunk is parked: publish the sweep once the parking stores have been acknowledged
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&sweeps_done[cur_chunk], sw_index + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur_chunk = PT_NONE;
+            }
             if ((uint32_t)__popcll(m) < pp.refill_min) m = 0ull;  // wait until enough lanes are free: newcomers share a tile
             while (m != 0ull && !exhausted) {
                 if (chunk_next == chunk_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&counters->next_path, pp.chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= total) {
-                        exhausted = true;
-                        break;
+                    if (item == PT_NONE) {
+                        uint32_t q = 0;
+                        if (lane == 0) q = atomicAdd(&counters->next_path, 1u);
+                        q = __builtin_amdgcn_readfirstlane(q);
+                        if (q >= n_items) {
+                            exhausted = true;
+                            break;
+                        }
+                        item = q;
                     }
-                    chunk_next = base;
-                    chunk_end = (total - base < pp.chunk) ? total : base + pp.chunk;
+                    const uint32_t j = item / n_chunks_total, c = item - j * n_chunks_total;
+                    if (j > 0u) {
+                        uint32_t v = 0;
+                        if (lane == 0) v = __hip_atomic_load(&sweeps_done[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = __builtin_amdgcn_readfirstlane(v);
+                        if (v < j) break;  // not yet: keep the item, run the lanes that have work, ask again next round
+                        asm volatile("" ::: "memory");
+                    }
+                    item = PT_NONE;
+                    sw_index = j;
+                    sw_begin = j ? pp.sweep_end[j - 1u] : 0u;
+                    sw_end = pp.sweep_end[j];
+                    chunk_next = c * pp.chunk;
+                    chunk_end = (total - chunk_next < pp.chunk) ? total : chunk_next + pp.chunk;
+                    if (pp.n_sweeps > 1u) cur_chunk = c;
+                    if (STATS) { if (n_chunks == 0) first_entry = chunk_next; n_chunks++; }
                 }
                 const uint32_t avail = chunk_end - chunk_next;
                 const uint32_t want = (uint32_t)__popcll(m);
@@ -273,7 +330,8 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
                 if (need && rank < take) {
                     need = false;
-                    const PathRec* r = &recs[chunk_next + rank];
+                    entry = chunk_next + rank;
+                    const PathRec* r = &recs[entry];
                     const float4 ra = r->a, rb = r->b, rc = r->c, rd = r->d;
                     pix = __float_as_uint(ra.x);
                     h.obj = __float_as_uint(ra.y);
@@ -287,9 +345,16 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                     slot[4 * 64] = h.n.x; slot[5 * 64] = h.n.y; slot[6 * 64] = h.n.z;
                     slot[7 * 64] = h.u; slot[8 * 64] = h.v;
                     slot[9 * 64] = rdir.x; slot[10 * 64] = rdir.y; slot[11 * 64] = rdir.z;
-                    sample = 0; bounce = 0;
+                    sample = sw_begin; bounce = 0;
                     nrays = 1;  // the primary ray, traced by k_primary
                     pixel_color = V3(0, 0, 0);
+                    if (sw_begin != 0u) {  // resume
+                        uint32_t* cw = carry[entry].w;
+                        rng.x = carry_load(cw + 0); rng.y = carry_load(cw + 1); rng.z = carry_load(cw + 2);
+                        nrays = carry_load(cw + 3);
+                        pixel_color = V3(__uint_as_float(carry_load(cw + 4)), __uint_as_float(carry_load(cw + 5)),
+                                         __uint_as_float(carry_load(cw + 6)));
+                    }
                     ray_color = V3(1, 1, 1);
                     color = V3(0, 0, 0);
                     rpos = origin;
@@ -297,10 +362,12 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 }
                 chunk_next += take;
                 m = __ballot(need);
+                if (cur_chunk != PT_NONE && chunk_next == chunk_end) break;  // sweeps: one chunk per wave at a time
             }
         }
         if (!__any(st != PT_ST_IDLE)) {
             if (exhausted) break;
+            if (item != PT_NONE) __builtin_amdgcn_s_sleep(16);
             continue;
         }
 
@@ -340,10 +407,19 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 if (end_path) {
                     pixel_color = add3(pixel_color, color);
                     sample++;
-                    if (sample >= samples) {
-                        out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
-                        // queries the reference would have run: it re-traces the primary ray for every sample
-                        aux_rays[pix] = nrays + samples - 1u;
+                    if (sample >= sw_end) {
+                        if (sw_end >= samples) {
+                            out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
+                            // queries the reference would have run: it re-traces the primary ray for every sample
+                            aux_rays[pix] = nrays + samples - 1u;
+                        } else {
+                            // park the pixel until its next sweep
+                            uint32_t* cw = carry[entry].w;
+                            carry_store(cw + 0, rng.x); carry_store(cw + 1, rng.y); carry_store(cw + 2, rng.z);
+                            carry_store(cw + 3, nrays);
+                            carry_store(cw + 4, __float_as_uint(pixel_color.x)); carry_store(cw + 5, __float_as_uint(pixel_color.y));
+                            carry_store(cw + 6, __float_as_uint(pixel_color.z));
+                        }
                         st = PT_ST_IDLE;
                         pending = false;
                     } else {
@@ -374,7 +450,11 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
         if (__any(st == PT_ST_TRACE)) {
             const bool tracing = st == PT_ST_TRACE;
             Best b;
+            cnt.passes = 0;
             closest_hit<MODE, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
+            // waves whose rays are expensive (many candidate objects) are the critical path of the launch: let them issue first
+            if (cnt.passes >= PT_WAVE_PRIO_PASSES) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
             if (tracing) {
                 nrays++;
                 lane_rays++;
@@ -402,6 +482,15 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             atomicMax(&counters->wave_life_max, life);
             { unsigned long long bkt = life >> 19; if (bkt > 31) bkt = 31; atomicAdd(&counters->life_hist[bkt], 1u); }
             if (n_rounds) atomicAdd(&counters->waves, 1ull);
+            if (wave_log) {
+                // per-wave record: start and end on the 100 MHz clock, lifetime in 16-cycle units, rounds; lane rounds,
+                // first list position, chunks taken << 8 | XCC_ID, HW_ID
+                const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+                const uint32_t xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+                uint4* rec = wave_log + 2u * (blockIdx.x * 4u + wave);
+                rec[0] = make_uint4((uint32_t)t_begin_real, (uint32_t)__builtin_amdgcn_s_memrealtime(), (uint32_t)(life >> 4), (uint32_t)n_rounds);
+                rec[1] = make_uint4((uint32_t)lane_rounds, first_entry, (n_chunks << 8) | (xcc_id & 15u), hw_id);
+            }
             atomicAdd(&counters->cyc_refill, cyc_refill);
             atomicAdd(&counters->cyc_trace, cyc_trace);
             atomicAdd(&counters->cyc_shade, cyc_shade);
@@ -442,7 +531,7 @@ __global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_d
         ro = V3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
         rd = V3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
     }
-    LaneCounters cnt = {0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
     Best b;
     closest_hit<MODE, false>(sc, ro, rd, valid, b, stk, cnt);
     if (!valid) return;

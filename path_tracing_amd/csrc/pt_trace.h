@@ -29,6 +29,7 @@ struct HitInfo {
 
 struct LaneCounters {
     uint32_t xforms, box_tests, tri_tests, shades, hits;
+    uint32_t passes;  // wave-uniform: object-test passes the wave made in its last closest_hit (a measure of how expensive its rays are)
 };
 
 // Per-lane traversal stack in LDS: entry [level][lane], so a wave's push/pop touches 64 consecutive banks.
@@ -166,6 +167,8 @@ PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t root, const Sla
 // The reference gates the whole mesh on hit_box() BEFORE looking at triangles; the gate only ever rejects, so it
 // is evaluated afterwards and only for objects that produced a winning candidate (the exact arithmetic with its
 // three divisions is then needed once per accepted object instead of once per visited object).
+// Meshes without a BLAS and more than this many triangles are first tested against their padded local box.
+#define PT_LOCAL_BOX_MIN_TRIS 4u
 template <bool STATS, bool PERLANE>
 PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& best, LdsStack stk, int sp0,
                         LaneCounters& cnt) {
@@ -181,15 +184,21 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
         // scene records live in LDS: every lane reads its own mesh and triangles, no grouping by mesh needed
         const DMesh* me = &sc.meshes[mesh_id];
         const uint32_t root = me->blas_root, tri_first = me->tri_first;
+        const float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) + me->max_abs);
+        const SlabRay sr = make_slab_ray(lo, ld, pad);
         if (root == PT_NONE) {
+            // no BLAS: the padded mesh box stands in for its root (the same test a BLAS walk starts with)
             const uint32_t n = me->tri_count;
+            float tn;
+            if (STATS) cnt.box_tests++;
+            if (n > PT_LOCAL_BOX_MIN_TRIS &&
+                !slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn))
+                return;
             for (uint32_t i = 0; i < n; ++i) {
                 const DTri* T = &sc.tris[tri_first + i];
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
             }
         } else {
-            const float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) + me->max_abs);
-            const SlabRay sr = make_slab_ray(lo, ld, pad);
             bvh_walk<STATS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
                 const DTri* T = &sc.tris[tri_first + tri];
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
@@ -213,15 +222,21 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                 pending = false;
                 const DMesh* me = &sc.meshes[m];
                 const uint32_t root = me->blas_root, tri_first = me->tri_first;
+                const float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) + me->max_abs);
+                const SlabRay sr = make_slab_ray(lo, ld, pad);
                 if (root == PT_NONE) {
                     const uint32_t n = me->tri_count;
-                    for (uint32_t i = 0; i < n; ++i) {
-                        const DTri* T = &sc.tris[tri_first + i];
-                        changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
+                    float tn;
+                    if (STATS) cnt.box_tests++;
+                    const bool inside = n <= PT_LOCAL_BOX_MIN_TRIS ||
+                        slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn);
+                    if (__any(inside)) {
+                        for (uint32_t i = 0; i < n; ++i) {
+                            const DTri* T = &sc.tris[tri_first + i];
+                            if (inside) changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
+                        }
                     }
                 } else {
-                    const float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) + me->max_abs);
-                    const SlabRay sr = make_slab_ray(lo, ld, pad);
                     bvh_walk<STATS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
                         const DTri* T = &sc.tris[tri_first + tri];
                         changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
@@ -253,21 +268,30 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
     for (uint32_t base = 0; base < n; base += 32) {
         const uint32_t m = (n - base < 32u) ? n - base : 32u;
         uint32_t mask = 0;
+        uint32_t near_k = 0;      // the candidate whose box the ray enters first is tested first: it usually holds the
+        float near_t = PT_T_MAX;  // closest hit, and the others are then culled by distance
         if (cull) {
             for (uint32_t k = 0; k < m; ++k) {
                 const float4 blo = sc.obj_lo[base + k], bhi = sc.obj_hi[base + k];
                 float tn;
                 if (STATS) cnt.box_tests++;
-                if (slab_test(sr, blo, bhi, best.t, tn)) mask |= 1u << k;
+                if (slab_test(sr, blo, bhi, best.t, tn)) {
+                    mask |= 1u << k;
+                    if (tn < near_t) { near_t = tn; near_k = k; }
+                }
             }
         } else {
             mask = (m == 32u) ? 0xFFFFFFFFu : ((1u << m) - 1u);
         }
         if (!active) mask = 0;
+        bool first = cull;
         while (__any(mask != 0)) {
+            cnt.passes++;
             if (mask != 0) {
-                const uint32_t o = base + (uint32_t)__builtin_ctz(mask);
-                mask &= mask - 1;
+                const uint32_t k = first ? near_k : (uint32_t)__builtin_ctz(mask);
+                first = false;
+                const uint32_t o = base + k;
+                mask &= ~(1u << k);
                 float tn;
                 if (!cull || slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn)) object_test<STATS, PERLANE>(sc, o, ro, rd, best, stk, 0, cnt);
             }
