@@ -268,10 +268,10 @@ class Context:
         return st.as_dict()
 
     def wave_log(self) -> np.ndarray:
-        """Per-wave records (n, 8) u32 of the last frame rendered with detailed statistics."""
+        """Per-wave records (n, 16) u32 of the last frame rendered with detailed statistics."""
         n = C.c_uint32(0)
         self._check(self._lib.pt_debug_wave_log(self._h, None, 0, C.byref(n)))
-        out = np.zeros((n.value, 8), dtype=np.uint32)
+        out = np.zeros((n.value, 16), dtype=np.uint32)
         if n.value:
             self._check(self._lib.pt_debug_wave_log(self._h, _ptr(out), out.nbytes, C.byref(n)))
         return out

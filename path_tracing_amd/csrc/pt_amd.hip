@@ -44,6 +44,13 @@ struct DevBuf {
 
 }  // namespace
 
+// What a frame's per-pixel costs depend on (besides the seeds): compared bytewise.
+struct FrameKey {
+    uint64_t scene_version;
+    uint32_t width, height, samples, bounces, part_index, part_count;
+    float wfv[16], vfc[16];
+};
+
 struct pt_ctx {
     PtConfig cfg{};
     int device = 0;
@@ -62,7 +69,7 @@ struct pt_ctx {
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors;
     // frame outputs
-    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_sweeps_done, d_carry, d_wave_log;
+    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
@@ -79,6 +86,10 @@ struct pt_ctx {
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
     uint32_t wave_log_records = 0;
     uint32_t max_sweeps = 5;      // see PathParams::n_sweeps
+    bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
+    bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
+    FrameKey hint_key;
+    uint64_t scene_version = 0;   // bumped by every upload
     uint32_t aux_w = 0, aux_h = 0;
     uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
     bool stats_detail = false;
@@ -175,6 +186,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         ctx->device = cfg->device;
         ctx->n_cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
         if (const char* e = std::getenv("PT_AMD_REFILL_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_min = (uint32_t)v; }
+        if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; }
         std::snprintf(ctx->info, sizeof ctx->info, "pt_amd abi %d | %s %s | %d CUs | %d MHz | %.0f GiB", PT_ABI_VERSION, prop.name,
@@ -211,7 +223,7 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
-                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_wave_log};
+                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -336,6 +348,7 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
         ctx->n_blas_nodes = n_nodes;
         ctx->max_blas_depth = max_depth;
         ctx->have_meshes = true;
+        ctx->scene_version++;
         ctx->acc_frames = 0;
         // instance data depends on the mesh table (world boxes, flat triangle ids)
         if (ctx->have_objects) return rebuild_objects(ctx);
@@ -375,6 +388,7 @@ int pt_upload_materials(pt_ctx* ctx, const PtMaterial* materials, uint32_t n_mat
         ctx->n_textures = n_textures;
         ctx->n_texdata = n_texture_data;
         ctx->have_materials = true;
+        ctx->scene_version++;
         ctx->acc_frames = 0;
         return PT_OK;
     } catch (...) {
@@ -395,6 +409,7 @@ int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects) 
         }
         ctx->h_objects.assign(objects, objects + n_objects);
         ctx->have_objects = true;
+        ctx->scene_version++;
         ctx->acc_frames = 0;
         if (!ctx->have_meshes) {  // instance data is derived once the mesh table exists
             ctx->n_objects = n_objects;
@@ -639,6 +654,21 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     }
     // path list: at most one entry per pixel of this partition
     PT_HIP(ctx, ctx->d_paths.ensure(sizeof(PathRec) * (size_t)fp.n_local_tiles * 64));
+    PT_HIP(ctx, ctx->d_cost.ensure(sizeof(uint32_t) * (size_t)fp.n_local_tiles * 64));
+    // Per-pixel ray counts of the previous frame, still in the aux plane, predict what this frame's pixels cost when
+    // it is the same view of the same scene (the usual case: a renderer that draws frame after frame). They only
+    // decide the order in which k_paths takes the pixels, never a result.
+    FrameKey key;
+    std::memset(&key, 0, sizeof key);
+    key.scene_version = ctx->scene_version;
+    key.width = f->width; key.height = f->height;
+    key.samples = f->settings.samples; key.bounces = f->settings.bounces;
+    key.part_index = f->part_index; key.part_count = pc;
+    std::memcpy(key.wfv, f->world_from_view, sizeof key.wfv);
+    std::memcpy(key.vfc, f->view_from_clip, sizeof key.vfc);
+    const bool use_hint = ctx->hint_valid && std::memcmp(&key, &ctx->hint_key, sizeof key) == 0 && ctx->cost_hints &&
+                          f->settings.samples >= 8u && f->settings.bounces > 1u;
+    ctx->hint_valid = false;   // until this frame has been enqueued completely
     SceneView sv = make_view(ctx);
     const uint32_t depth = stack_depth_needed(ctx);
     const bool st = ctx->stats_detail;
@@ -657,12 +687,12 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     {
         const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
         const uint32_t grid = div_up(fp.n_local_tiles, 4);
-        using PrimaryFn = void (*)(PT_SCENE_PARAMS, LdsScene, FrameParams, uint32_t, float4*, uint32_t*, uint32_t*, float*, uint32_t*, PathRec*, DCounters*);
+        using PrimaryFn = void (*)(PT_SCENE_PARAMS, LdsScene, FrameParams, uint32_t, float4*, uint32_t*, uint32_t*, float*, uint32_t*, PathRec*, uint32_t*, uint32_t, DCounters*);
         static const PrimaryFn table[3][2] = {{k_primary<PT_MODE_LIST, false>, k_primary<PT_MODE_LIST, true>},
                                               {k_primary<PT_MODE_TLAS, false>, k_primary<PT_MODE_TLAS, true>},
                                               {k_primary<PT_MODE_LDS, false>, k_primary<PT_MODE_LDS, true>}};
         if (grid) {
-            table[mode][st ? 1 : 0]<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, fp, depth, o4, ao, af, at, ar, recs, dc);
+            table[mode][st ? 1 : 0]<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, fp, depth, o4, ao, af, at, ar, recs, ctx->d_cost.as<uint32_t>(), use_hint ? 1u : 0u, dc);
             PT_HIP(ctx, hipGetLastError());
         }
     }
@@ -679,7 +709,8 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
         pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
         const size_t lds = (size_t)4 * (depth + PT_LANE_SLOTS) * 64 * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
-        using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, PathParams, uint32_t, const PathRec*, PathCarry*, uint32_t*, float4*, uint32_t*, DCounters*, uint4*);
+        using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, PathParams, uint32_t, const PathRec*, PathCarry*, uint32_t*, const uint32_t*, const ChunkOrderInfo*, float4*,
+                                 uint32_t*, DCounters*, uint4*);
         static const PathsFn ptable[3][2] = {{k_paths<PT_MODE_LIST, false>, k_paths<PT_MODE_LIST, true>},
                                              {k_paths<PT_MODE_TLAS, false>, k_paths<PT_MODE_TLAS, true>},
                                              {k_paths<PT_MODE_LDS, false>, k_paths<PT_MODE_LDS, true>}};
@@ -713,17 +744,33 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         uint4* wlog = nullptr;
         ctx->wave_log_records = 0;
         if (st) {
-            PT_HIP(ctx, ctx->d_wave_log.ensure((size_t)32 * grid * 4));
-            PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_log.p, 0, (size_t)32 * grid * 4, s));
+            PT_HIP(ctx, ctx->d_wave_log.ensure((size_t)64 * grid * 4));
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_log.p, 0, (size_t)64 * grid * 4, s));
             wlog = ctx->d_wave_log.as<uint4>();
             ctx->wave_log_records = grid * 4u;
         }
         if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u sweeps=%u\n", mode, per_cu, grid, lds, depth, pp.chunk, pp.refill_min, pp.n_sweeps);
-        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, pp, depth, recs, ctx->d_carry.as<PathCarry>(), ctx->d_sweeps_done.as<uint32_t>(), o4, ar, dc, wlog);
+        const uint32_t* chunk_order = nullptr;
+        const ChunkOrderInfo* order_info = nullptr;
+        if (use_hint && pp.chunk == PT_CHUNK) {
+            const uint32_t max_chunks = fp.n_local_tiles;   // 64 entries per tile at most
+            PT_HIP(ctx, ctx->d_chunk_bin.ensure(sizeof(uint32_t) * max_chunks));
+            PT_HIP(ctx, ctx->d_chunk_order.ensure(sizeof(uint32_t) * max_chunks + sizeof(ChunkOrderInfo)));
+            uint32_t* order = ctx->d_chunk_order.as<uint32_t>();
+            ChunkOrderInfo* info = reinterpret_cast<ChunkOrderInfo*>(order + max_chunks);
+            k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(ctx->d_cost.as<uint32_t>(), dc, fp.samples, ctx->d_chunk_bin.as<uint32_t>());
+            k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info);
+            chunk_order = order;
+            order_info = info;
+        }
+        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, pp, depth, recs, ctx->d_carry.as<PathCarry>(), ctx->d_sweeps_done.as<uint32_t>(), chunk_order,
+                                  order_info, o4, ar, dc, wlog);
         PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, s));
     ctx->timing_pending = true;
+    ctx->hint_key = key;
+    ctx->hint_valid = f->settings.samples > 0u && f->settings.bounces > 0u;
     // pixels of this partition
     uint64_t local_pixels = 0;
     if (pc == 1) {
@@ -852,7 +899,7 @@ int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n
         int rc = finish_timing(ctx);
         if (rc != PT_OK) return rc;
         *n_records = ctx->wave_log_records;
-        const size_t bytes = std::min(out_bytes, (size_t)32 * ctx->wave_log_records);
+        const size_t bytes = std::min(out_bytes, (size_t)64 * ctx->wave_log_records);
         if (out_host && bytes) PT_HIP(ctx, hipMemcpy(out_host, ctx->d_wave_log.p, bytes, hipMemcpyDeviceToHost));
         return PT_OK;
     } catch (...) {

@@ -115,7 +115,8 @@ template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, FrameParams fp, uint32_t stack_depth, float4* __restrict__ out,
                                                  uint32_t* __restrict__ aux_obj, uint32_t* __restrict__ aux_flat,
                                                  float* __restrict__ aux_t, uint32_t* __restrict__ aux_rays,
-                                                 PathRec* __restrict__ recs, DCounters* __restrict__ counters) {
+                                                 PathRec* __restrict__ recs, uint32_t* __restrict__ cost, uint32_t use_hint,
+                                                 DCounters* __restrict__ counters) {
     PT_SCENE_VIEW_FROM_PARAMS()
     extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes], then the staged scene (PT_MODE_LDS)
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + 4 * stack_depth * 64);
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, F
     Best b;
     closest_hit<MODE, STATS>(sc, origin, dir0, valid, b, stk, cnt);
     bool to_list = false;
+    uint32_t hint = 0;  // rays beyond one per sample that this pixel took in the previous frame (0 when unknown)
     HitInfo h;
     h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
     if (valid) {
@@ -179,6 +181,11 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, F
             aux_rays[pix] = samples;  // the reference traces the primary ray once per sample
         } else {
             to_list = true;
+            if (use_hint) {
+                // aux_rays still holds the previous frame's count for this pixel: rays + samples - 1 (k_paths writes it)
+                const uint32_t prev = aux_rays[pix];
+                hint = prev > 2u * samples ? prev - 2u * samples : 0u;
+            }
         }
     }
     // append the workgroup's surviving pixels to the path list: one atomic per workgroup (a single counter takes
@@ -201,7 +208,9 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, F
             r.b = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
             r.c = make_float4(h.n.y, h.n.z, dir0.x, dir0.y);
             r.d = make_float4(dir0.z, __uint_as_float(seed_x), __uint_as_float(seed_y), __uint_as_float(seed_z));
-            recs[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            recs[pos] = r;
+            cost[pos] = hint;
         }
     }
     // (the primary rays, one per pixel of the partition, are added to the ray count on the host)
@@ -215,6 +224,54 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, F
             atomicAdd(&counters->hits, (unsigned long long)e);
         }
     }
+}
+
+// ---- order of the chunks ---------------------------------------------------------------------------------------
+// A chunk is PT_CHUNK consecutive list entries. k_chunk_keys gives every chunk a cost bin from the per-pixel hints
+// (mean rays beyond one per sample, 1/8 ray per sample per bin, 32 bins); k_chunk_order (one workgroup) sorts the
+// chunk numbers by descending bin with a counting sort and reports how many chunks count as expensive.
+#define PT_CHUNK 64u
+#define PT_COST_BINS 32u
+#define PT_HEAVY_BIN 2u   // chunks from this bin up (0.25 extra rays per sample) are run in one piece, first
+struct ChunkOrderInfo {
+    uint32_t n_chunks, n_heavy;
+};
+__global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__ cost, const DCounters* __restrict__ counters,
+                                                    uint32_t samples, uint32_t* __restrict__ chunk_bin) {
+    const uint32_t total = counters->n_paths;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * 4u + wave;
+    if (c * PT_CHUNK >= total) return;
+    const uint32_t i = c * PT_CHUNK + lane;
+    uint32_t v = (i < total) ? cost[i] : 0u;
+    uint32_t n = (i < total) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); n += __shfl_xor(n, off, 64); }
+    if (lane == 0) {
+        const uint32_t bin = (v * 8u) / (n * samples);
+        chunk_bin[c] = bin < PT_COST_BINS ? bin : PT_COST_BINS - 1u;
+    }
+}
+__global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict__ chunk_bin, const DCounters* __restrict__ counters,
+                                                      uint32_t* __restrict__ order, ChunkOrderInfo* __restrict__ info) {
+    __shared__ uint32_t cnt[PT_COST_BINS], start[PT_COST_BINS];
+    const uint32_t total = counters->n_paths;
+    const uint32_t n_chunks = (total + PT_CHUNK - 1u) / PT_CHUNK;
+    if (threadIdx.x < PT_COST_BINS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024u) atomicAdd(&cnt[chunk_bin[c]], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, heavy = 0;
+        for (int b = (int)PT_COST_BINS - 1; b >= 0; --b) {   // most expensive bin first
+            start[b] = run;
+            run += cnt[b];
+            if ((uint32_t)b >= PT_HEAVY_BIN) heavy = run;
+        }
+        info->n_chunks = n_chunks;
+        info->n_heavy = heavy;
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024u) order[atomicAdd(&start[chunk_bin[c]], 1u)] = c;
 }
 
 // ---- path pass -----------------------------------------------------------------------------------------------
@@ -237,7 +294,8 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, F
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, PathParams pp, uint32_t stack_depth,
                                                                     const PathRec* __restrict__ recs, PathCarry* __restrict__ carry,
-                                                                    uint32_t* __restrict__ sweeps_done,
+                                                                    uint32_t* __restrict__ sweeps_done, const uint32_t* __restrict__ chunk_order,
+                                                                    const ChunkOrderInfo* __restrict__ order_info,
                                                                     float4* __restrict__ out, uint32_t* __restrict__ aux_rays,
                                                                     DCounters* __restrict__ counters, uint4* __restrict__ wave_log) {
     PT_SCENE_VIEW_FROM_PARAMS()
@@ -276,9 +334,16 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     uint32_t item = PT_NONE;                 // queue item taken but not started: the chunk's previous sweep is still running elsewhere
     uint32_t cur_chunk = PT_NONE;            // chunk whose sweep this wave has to report as complete (n_sweeps > 1)
     uint32_t sw_index = 0, sw_begin = 0, sw_end = samples;
+    // Queue: first every chunk once, most expensive first (chunk_order): the n_heavy expensive ones with all their
+    // samples, so that the longest chains of dependent rays start at once and run through; the others with their
+    // first sweep; then sweep after sweep over the others.
     const uint32_t n_chunks_total = (total + pp.chunk - 1u) / pp.chunk;
-    const uint32_t n_items = n_chunks_total * pp.n_sweeps;
+    const uint32_t n_heavy = (order_info && pp.n_sweeps > 1u) ? order_info->n_heavy : 0u;
+    const uint32_t n_light = n_chunks_total - n_heavy;
+    const uint32_t n_items = n_chunks_total + (pp.n_sweeps - 1u) * n_light;
     uint32_t first_entry = 0xFFFFFFFFu, n_chunks = 0;  // STATS only
+    unsigned long long item_t0 = 0, item_r0 = 0, worst_cycles = 0, worst_rounds = 0;  // STATS only: the wave's longest item
+    uint32_t worst_item = 0, cur_item = 0;
     unsigned long long cyc_refill = 0, cyc_trace = 0, cyc_shade = 0, n_rounds = 0, lane_rounds = 0;  // STATS only
 
     for (;;) {
@@ -307,7 +372,13 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                         }
                         item = q;
                     }
-                    const uint32_t j = item / n_chunks_total, c = item - j * n_chunks_total;
+                    uint32_t j = 0, cpos = item;   // sweep, position in the chunk order
+                    if (item >= n_chunks_total) {
+                        const uint32_t r = item - n_chunks_total;
+                        j = 1u + r / n_light;
+                        cpos = n_heavy + (r - (j - 1u) * n_light);
+                    }
+                    const uint32_t c = chunk_order ? chunk_order[cpos] : cpos;
                     if (j > 0u) {
                         uint32_t v = 0;
                         if (lane == 0) v = __hip_atomic_load(&sweeps_done[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -315,14 +386,22 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                         if (v < j) break;  // not yet: keep the item, run the lanes that have work, ask again next round
                         asm volatile("" ::: "memory");
                     }
+                    const uint32_t this_item = item;
+                    (void)this_item;
                     item = PT_NONE;
                     sw_index = j;
                     sw_begin = j ? pp.sweep_end[j - 1u] : 0u;
-                    sw_end = pp.sweep_end[j];
+                    sw_end = (cpos < n_heavy) ? samples : pp.sweep_end[j];
                     chunk_next = c * pp.chunk;
                     chunk_end = (total - chunk_next < pp.chunk) ? total : chunk_next + pp.chunk;
-                    if (pp.n_sweeps > 1u) cur_chunk = c;
-                    if (STATS) { if (n_chunks == 0) first_entry = chunk_next; n_chunks++; }
+                    if (pp.n_sweeps > 1u && cpos >= n_heavy) cur_chunk = c;
+                    if (STATS) {
+                        if (n_chunks == 0) first_entry = chunk_next;
+                        const unsigned long long now = __builtin_amdgcn_s_memtime();
+                        if (n_chunks != 0 && now - item_t0 > worst_cycles) { worst_cycles = now - item_t0; worst_rounds = n_rounds - item_r0; worst_item = cur_item; }
+                        item_t0 = now; item_r0 = n_rounds; cur_item = this_item;
+                        n_chunks++;
+                    }
                 }
                 const uint32_t avail = chunk_end - chunk_next;
                 const uint32_t want = (uint32_t)__popcll(m);
@@ -373,67 +452,86 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
 
         // ---- B. shade (src/raytrace.wgsl:229-270) and advance (sample, bounce) ----------------------------------
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
+        // A path that stops moves on to the pixel's next sample, whose first hit is the cached primary hit.
+        // Returns false when the lane has run the last sample of its sweep.
+        auto next_sample = [&]() -> bool {
+            pixel_color = add3(pixel_color, color);
+            sample++;
+            if (sample >= sw_end) {
+                if (sw_end >= samples) {
+                    out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
+                    // queries the reference would have run: it re-traces the primary ray for every sample
+                    aux_rays[pix] = nrays + samples - 1u;
+                } else {
+                    // park the pixel until its next sweep
+                    uint32_t* cw = carry[entry].w;
+                    carry_store(cw + 0, rng.x); carry_store(cw + 1, rng.y); carry_store(cw + 2, rng.z);
+                    carry_store(cw + 3, nrays);
+                    carry_store(cw + 4, __float_as_uint(pixel_color.x)); carry_store(cw + 5, __float_as_uint(pixel_color.y));
+                    carry_store(cw + 6, __float_as_uint(pixel_color.z));
+                }
+                st = PT_ST_IDLE;
+                return false;
+            }
+            bounce = 0;
+            rpos = origin;
+            rdir = V3(slot[9 * 64], slot[10 * 64], slot[11 * 64]);
+            ray_color = V3(1, 1, 1);
+            color = V3(0, 0, 0);
+            h.obj = __float_as_uint(slot[0]);
+            h.p = V3(slot[1 * 64], slot[2 * 64], slot[3 * 64]);
+            h.n = V3(slot[4 * 64], slot[5 * 64], slot[6 * 64]);
+            h.u = slot[7 * 64];
+            h.v = slot[8 * 64];
+            return true;
+        };
+        // what the surface emits, and whether the path stops on it (black albedo)
+        auto add_emitted = [&]() -> bool {
+            const DMaterial* m = &sc.materials[sc.objects[h.obj].mat];
+            v3 emissive = V3(m->emissive[0], m->emissive[1], m->emissive[2]);
+            const uint32_t et = m->emissive_texture;
+            if (et != PT_NONE) emissive = sample_texture(sc, et, h.u, h.v);
+            color = V3(pt_fma(ray_color.x, emissive.x, color.x), pt_fma(ray_color.y, emissive.y, color.y),
+                       pt_fma(ray_color.z, emissive.z, color.z));
+            const v3 alb = V3(m->albedo[0], m->albedo[1], m->albedo[2]);
+            return dot3(alb, alb) < PT_EPSILON;
+        };
         bool pending = st == PT_ST_SHADE;
         while (__any(pending)) {
+            // 1. (cheap) a path that ends on this hit, a miss or a black surface, restarts from the primary hit ...
+            bool restarted = false;
             if (pending) {
-                bool end_path = false;
+                bool stop;
                 if (h.obj != PT_NONE) {
-                    const DMaterial m = sc.materials[sc.objects[h.obj].mat];
-                    v3 emissive = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
-                    if (m.emissive_texture != PT_NONE) emissive = sample_texture(sc, m.emissive_texture, h.u, h.v);
-                    color = V3(pt_fma(ray_color.x, emissive.x, color.x), pt_fma(ray_color.y, emissive.y, color.y),
-                               pt_fma(ray_color.z, emissive.z, color.z));
-                    const v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
-                    if (dot3(alb, alb) < PT_EPSILON) {
-                        end_path = true;
-                    } else {
-                        v3 N = h.n;
-                        if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
-                        v3 ndir, bcol;
-                        if (STATS) cnt.shades++;
-                        calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
-                        rdir = ndir;
-                        rpos = madd3(h.p, rdir, 0.001f);
-                        ray_color = mul3(ray_color, bcol);
-                        const float p = pt_max(ray_color.x, pt_max(ray_color.y, ray_color.z));
-                        bounce++;
-                        if (p < PT_EPSILON || bounce >= bounces) end_path = true;
-                    }
+                    stop = add_emitted();
                 } else {
                     color = V3(pt_fma(ray_color.x, sky.x, color.x), pt_fma(ray_color.y, sky.y, color.y),
                                pt_fma(ray_color.z, sky.z, color.z));
-                    end_path = true;
+                    stop = true;
                 }
-                if (end_path) {
-                    pixel_color = add3(pixel_color, color);
-                    sample++;
-                    if (sample >= sw_end) {
-                        if (sw_end >= samples) {
-                            out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
-                            // queries the reference would have run: it re-traces the primary ray for every sample
-                            aux_rays[pix] = nrays + samples - 1u;
-                        } else {
-                            // park the pixel until its next sweep
-                            uint32_t* cw = carry[entry].w;
-                            carry_store(cw + 0, rng.x); carry_store(cw + 1, rng.y); carry_store(cw + 2, rng.z);
-                            carry_store(cw + 3, nrays);
-                            carry_store(cw + 4, __float_as_uint(pixel_color.x)); carry_store(cw + 5, __float_as_uint(pixel_color.y));
-                            carry_store(cw + 6, __float_as_uint(pixel_color.z));
-                        }
-                        st = PT_ST_IDLE;
-                        pending = false;
-                    } else {
-                        bounce = 0;
-                        rpos = origin;
-                        rdir = V3(slot[9 * 64], slot[10 * 64], slot[11 * 64]);
-                        ray_color = V3(1, 1, 1);
-                        color = V3(0, 0, 0);
-                        h.obj = __float_as_uint(slot[0]);
-                        h.p = V3(slot[1 * 64], slot[2 * 64], slot[3 * 64]);
-                        h.n = V3(slot[4 * 64], slot[5 * 64], slot[6 * 64]);
-                        h.u = slot[7 * 64];
-                        h.v = slot[8 * 64];
-                    }
+                if (stop) {
+                    pending = next_sample();
+                    restarted = pending;
+                }
+            }
+            // 2. ... whose surface never ends a path (k_primary finished those pixels)
+            if (restarted) (void)add_emitted();
+            // 3. (expensive) so every lane that still has work scatters in the same pass
+            if (pending) {
+                const DMaterial m = sc.materials[sc.objects[h.obj].mat];
+                v3 N = h.n;
+                if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
+                v3 ndir, bcol;
+                if (STATS) cnt.shades++;
+                calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
+                rdir = ndir;
+                rpos = madd3(h.p, rdir, 0.001f);
+                ray_color = mul3(ray_color, bcol);
+                const float p = pt_max(ray_color.x, pt_max(ray_color.y, ray_color.z));
+                bounce++;
+                if (p < PT_EPSILON || bounce >= bounces) {
+                    // dark path or bounce limit: next sample; its primary hit is shaded in another pass of this loop
+                    pending = next_sample();
                 } else {
                     st = PT_ST_TRACE;
                     pending = false;
@@ -484,12 +582,18 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             if (n_rounds) atomicAdd(&counters->waves, 1ull);
             if (wave_log) {
                 // per-wave record: start and end on the 100 MHz clock, lifetime in 16-cycle units, rounds; lane rounds,
-                // first list position, chunks taken << 8 | XCC_ID, HW_ID
+                // first list position, items taken << 8 | XCC_ID, HW_ID; the wave's longest item: 16-cycle units, rounds, index
                 const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
                 const uint32_t xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
-                uint4* rec = wave_log + 2u * (blockIdx.x * 4u + wave);
+                uint4* rec = wave_log + 4u * (blockIdx.x * 4u + wave);
                 rec[0] = make_uint4((uint32_t)t_begin_real, (uint32_t)__builtin_amdgcn_s_memrealtime(), (uint32_t)(life >> 4), (uint32_t)n_rounds);
+                {
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    if (n_chunks != 0 && now - item_t0 > worst_cycles) { worst_cycles = now - item_t0; worst_rounds = n_rounds - item_r0; worst_item = cur_item; }
+                }
                 rec[1] = make_uint4((uint32_t)lane_rounds, first_entry, (n_chunks << 8) | (xcc_id & 15u), hw_id);
+                rec[2] = make_uint4((uint32_t)(worst_cycles >> 4), (uint32_t)worst_rounds, worst_item, 0u);
+                rec[3] = make_uint4(0u, 0u, 0u, 0u);
             }
             atomicAdd(&counters->cyc_refill, cyc_refill);
             atomicAdd(&counters->cyc_trace, cyc_trace);

@@ -73,7 +73,12 @@ def hw_report():
     print("slowest CUs: key, cyc/round, last end, waves, rounds")
     for i in o[-8:]:
         print("   ", per_cu[i].round(1).tolist())
-    late = np.argsort(end)[-24:]
+    wc = lg[:, 8].astype(np.int64) * 16; wr = lg[:, 9].astype(np.int64)
+    o2 = np.argsort(wc)[-12:]
+    print("longest items: cycles (M), us at 2.4 GHz, rounds, cycles/round, queue index, wave end")
+    for i in o2:
+        print(f"    {wc[i]/1e6:.2f}M {wc[i]/2400:.0f}us rounds {wr[i]} cyc/round {wc[i]/max(1,wr[i]):.0f} item {lg[i,10]} end {end[i]:.0f}")
+    late = np.argsort(end)[-8:]
     for i in late:
         print(f"   late wave: end {end[i]:.0f} rounds {rounds[i]} cyc/round {cpr[i]:.0f} chunks {lg[i,6]>>8} xcc {xcc[i]} se {se[i]} sh {sh[i]} cu {cu[i]} simd {simd[i]}")
     ctx.close()
