@@ -144,11 +144,14 @@ def main():
     dt = time.perf_counter() - t0
 
     # kernel durations (HIP events recorded by the library on the launch stream), one step at a time
-    kernel_ms = []
+    kernel_ms, paths_ms, primary_ms = [], [], []
     for _ in range(args.steps):
         ctx.render_device(frame, out.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize(device)
-        kernel_ms.append(ctx.stats()["trace_ms"])
+        st = ctx.stats()
+        kernel_ms.append(st["trace_ms"])
+        paths_ms.append(st["paths_ms"])
+        primary_ms.append(st["primary_ms"])
     st = ctx.stats()
     mean_img = float(out[..., :3].mean().item())
 
@@ -172,9 +175,11 @@ def main():
     if rank == 0:
         ms_per_step = t_max / args.steps * 1e3
         value = rays_total / (t_max / args.steps) / 1e6
-        k_ms = float(np.mean(kernel_ms))
-        flops = sum(detail[k] * WORK[k][0] for k in WORK)
-        abytes = sum(detail[k] * WORK[k][1] for k in WORK) + W * H * 16
+        k_ms = float(np.mean(paths_ms))   # the dominant kernel: k_paths
+        # work of k_paths alone: the frame's counters minus what k_primary did
+        work = {k: int(detail[k]) - int(detail.get("primary_" + k, 0)) for k in WORK}
+        flops = sum(work[k] * WORK[k][0] for k in WORK)
+        abytes = sum(work[k] * WORK[k][1] for k in WORK) + W * H * 16
         # what must cross HBM at least once per frame: the scene arrays in, the image and the four aux planes out
         scene_bytes = sum(int(a.nbytes) for a in (scene.objects, scene.meshes, scene.indices, scene.vertices, scene.materials,
                                                   scene.textures, scene.texture_data))
@@ -210,14 +215,16 @@ def main():
             "mrays_reference_equiv_per_s": round(rays_ref_total / (t_max / args.steps) / 1e6, 1),
             "samples_per_s": round(paths_total / (t_max / args.steps), 1),
             "image_mean": round(mean_img, 6),
-            "roofline": {"bound": "valu", "kernel": "k_render", "achieved": round(achieved_tflops, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+            "kernels_ms": {"k_primary": round(float(np.mean(primary_ms)), 4), "k_paths": round(float(np.mean(paths_ms)), 4),
+                           "frame": round(float(np.mean(kernel_ms)), 4)},
+            "roofline": {"bound": "valu", "kernel": "k_paths", "achieved": round(achieved_tflops, 3), "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VALU_TFLOPS, 5),
                          "traffic": traffic,
                          "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": int(flops),
                          "on_chip_bytes_per_launch": int(abytes),
                          "hbm": {"compulsory_bytes_per_launch": int(compulsory), "achieved_GBs": round(compulsory / (k_ms * 1e-3) / 1e9, 2),
                                  "peak_GBs": PEAK_HBM_GBS, "frac": round(compulsory / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)},
-                         "counts": {k: int(detail[k]) for k in WORK}},
+                         "counts": work},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_spp, scene.samples))

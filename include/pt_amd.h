@@ -271,6 +271,8 @@ typedef struct PtStats {
     uint64_t cycles_refill, cycles_trace, cycles_shade, wave_rounds, lane_rounds;
     uint64_t wave_life_sum, wave_life_max, waves; /* lifetime of the path kernel's waves, shader cycles */
     uint32_t wave_life_hist[32];                  /* ... histogram, 2^19 cycles per bucket              */
+    /* detail only: the part of xforms / box_tests / tri_tests / hits done by the primary pass */
+    uint64_t primary_xforms, primary_box_tests, primary_tri_tests, primary_hits;
 } PtStats;
 
 /* detail != 0 re-runs nothing; it only selects whether the next renders also
@@ -283,8 +285,8 @@ int pt_device_info(pt_ctx* ctx, char* buf, size_t buf_bytes);
 
 /* Per-wave records of the last frame's k_paths launches when it was rendered with detailed statistics:
  * 16 x u32 per wave {start, end on the 100 MHz clock, lifetime in 16-cycle units, rounds, lane rounds, first list
- * position, items taken << 8 | XCC_ID, HW_ID, longest item: 16-cycle units, rounds, queue index, 5 x 0}. Copies at most out_bytes; *n_records = records available. Profiling aid, no counterpart in the
- * reference. */
+ * position, items taken << 8 | XCC_ID, HW_ID, longest item: 16-cycle units, rounds, queue index, 5 x 0}.
+ * Copies at most out_bytes; *n_records = records available. Profiling aid, no counterpart in the reference. */
 int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n_records);
 
 /* Diagnostics: verifies on the device that every node box of the TLAS and of every

@@ -69,7 +69,7 @@ struct pt_ctx {
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors;
     // frame outputs
-    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
+    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_counters_k1, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
@@ -93,6 +93,7 @@ struct pt_ctx {
     uint32_t aux_w = 0, aux_h = 0;
     uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
     bool stats_detail = false;
+    bool last_detail = false;     // the frame in flight was rendered with detailed statistics
     bool timing_pending = false;
     PtStats stats{};
     uint64_t last_paths = 0, last_primary = 0, last_primary_traced = 0;
@@ -199,6 +200,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb0);
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb1);
         if (e == hipSuccess) e = ctx->d_counters.ensure(sizeof(DCounters));
+        if (e == hipSuccess) e = ctx->d_counters_k1.ensure(sizeof(DCounters));
         if (e != hipSuccess) {
             std::string m = std::string("pt_create: ") + hipGetErrorString(e);
             pt_destroy(ctx);
@@ -223,7 +225,7 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
-                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
+                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_counters_k1, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -498,9 +500,12 @@ int rebuild_objects(pt_ctx* ctx) {
     return PT_OK;
 }
 
+// Entries of the per-lane traversal stack. A tree's depth is the number of internal nodes on its longest root-to-leaf
+// path; a walk pushes at most one entry per internal node it descends through, and a BLAS walk starts on top of
+// what the TLAS walk has pushed, so the depths add up. (LDS per workgroup decides how many fit on a compute unit.)
 uint32_t stack_depth_needed(const pt_ctx* ctx) {
-    uint32_t d = ctx->max_blas_depth + 1;
-    if (ctx->use_tlas) d += ctx->tlas_depth + 1;
+    uint32_t d = ctx->max_blas_depth;
+    if (ctx->use_tlas) d += ctx->tlas_depth;
     return std::max<uint32_t>(d, 2);
 }
 
@@ -558,6 +563,15 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.tri_tests = c.tri_tests;
     ctx->stats.shades = c.shades;
     ctx->stats.hits = c.hits;
+    ctx->stats.primary_xforms = ctx->stats.primary_box_tests = ctx->stats.primary_tri_tests = ctx->stats.primary_hits = 0;
+    if (ctx->last_detail) {
+        DCounters k1;
+        PT_HIP(ctx, hipMemcpy(&k1, ctx->d_counters_k1.p, sizeof k1, hipMemcpyDeviceToHost));
+        ctx->stats.primary_xforms = k1.xforms;
+        ctx->stats.primary_box_tests = k1.box_tests;
+        ctx->stats.primary_tri_tests = k1.tri_tests;
+        ctx->stats.primary_hits = k1.hits;
+    }
     ctx->stats.cycles_refill = c.cyc_refill;
     ctx->stats.cycles_trace = c.cyc_trace;
     ctx->stats.cycles_shade = c.cyc_shade;
@@ -672,6 +686,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     SceneView sv = make_view(ctx);
     const uint32_t depth = stack_depth_needed(ctx);
     const bool st = ctx->stats_detail;
+    ctx->last_detail = st;
     float4* o4 = reinterpret_cast<float4*>(out);
     uint32_t* ao = ctx->d_aux_obj.as<uint32_t>();
     uint32_t* af = ctx->d_aux_flat.as<uint32_t>();
@@ -696,6 +711,9 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
             PT_HIP(ctx, hipGetLastError());
         }
     }
+    if (st) {
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_counters_k1.p, ctx->d_counters.p, sizeof(DCounters), hipMemcpyDeviceToDevice, s));
+    }
     PT_HIP(ctx, hipEventRecord(ctx->evm, s));
     // 2. path pass: persistent waves, as many workgroups as fit on the chip at once (fewer for small frames); they
     //    pull list entries from a counter until the list is exhausted
@@ -708,7 +726,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         pp.chunk = ctx->chunk_pixels;
         // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
         pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
-        const size_t lds = (size_t)4 * (depth + PT_LANE_SLOTS) * 64 * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
+        const size_t lds = ((size_t)4 * (depth + PT_LANE_SLOTS) * 64 + 4 * PT_SCHED_WORDS) * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
         using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, PathParams, uint32_t, const PathRec*, PathCarry*, uint32_t*, const uint32_t*, const ChunkOrderInfo*, float4*,
                                  uint32_t*, DCounters*, uint4*);
         static const PathsFn ptable[3][2] = {{k_paths<PT_MODE_LIST, false>, k_paths<PT_MODE_LIST, true>},

@@ -278,18 +278,38 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
 // Persistent waves with per-lane refill. A lane owns one pixel at a time; across pixels nothing is shared. Every
 // round of the loop
 //   A. hands a new list entry to each idle lane (the wave owns a chunk of consecutive entries, i.e. pixels of a
-//      few neighbouring tiles, and takes the next chunk from a global counter when it runs out),
+//      few neighbouring tiles, and takes the next item from the work queue when it runs out),
 //   B. shades: every lane that holds a hit shades it; a lane whose path ends moves on to the pixel's next sample
-//      and shades the cached primary hit right away, until it holds a new ray or the pixel is complete,
+//      and shades the cached primary hit right away, until it holds a new ray or its samples are done,
 //   C. traces one ray for every lane that has one.
 // So the closest-hit code always runs with (nearly) all lanes, however uneven the path lengths are.
+//
+// Registers are the scarce resource (128 per lane at four waves per SIMD), so everything that is only touched when
+// a path ends or a chunk changes lives in LDS: per lane the cached primary hit, the pixel's radiance sum, the
+// samples left in its sweep, its list entry and pixel number; per wave the scheduling state.
 #define PT_ST_IDLE 0u
 #define PT_ST_SHADE 1u
 #define PT_ST_TRACE 2u
 #ifndef PT_WAVE_PRIO_PASSES
 #define PT_WAVE_PRIO_PASSES 2u  // object-test passes in a round from which a wave raises its issue priority
 #endif
-#define PT_LANE_SLOTS 12  // per-lane LDS words: primary hit record (9) + primary direction (3)
+// per-lane LDS words
+#define PT_SLOT_HIT 0        // primary hit record: object, p.xyz, n.xyz, uv (9 words)
+#define PT_SLOT_DIR 9        // primary ray direction (3)
+#define PT_SLOT_SUM 12       // radiance summed over the pixel's samples so far (3)
+#define PT_SLOT_LEFT 15      // samples left in this sweep
+#define PT_SLOT_ENTRY 16     // list entry; bit 31: this sweep ends the pixel
+#define PT_SLOT_PIX 17       // pixel number
+#define PT_LANE_SLOTS 18
+// per-wave LDS words (scheduling state)
+#define PT_SCHED_NEXT 0      // list entries of the current item not handed to lanes yet: [next, end)
+#define PT_SCHED_END 1
+#define PT_SCHED_ITEM 2      // queue item taken but not started (its chunk's previous sweep is still running elsewhere), or PT_NONE
+#define PT_SCHED_REPORT 3    // chunk whose sweep this wave has to report as complete, or PT_NONE
+#define PT_SCHED_SWEEP 4     // sweep of the current item
+#define PT_SCHED_BEGIN 5     // its first sample
+#define PT_SCHED_LEN 6       // its number of samples; bit 31: it ends the pixel
+#define PT_SCHED_WORDS 8
 
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, PathParams pp, uint32_t stack_depth,
@@ -299,48 +319,43 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                                                                     float4* __restrict__ out, uint32_t* __restrict__ aux_rays,
                                                                     DCounters* __restrict__ counters, uint4* __restrict__ wave_log) {
     PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes] stacks, [4 waves][PT_LANE_SLOTS][64 lanes], staged scene
-    if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + 4 * (stack_depth + PT_LANE_SLOTS) * 64);
+    // [4 waves][stack_depth][64 lanes] stacks, [4 waves][PT_LANE_SLOTS][64 lanes], [4 waves][PT_SCHED_WORDS], staged scene
+    extern __shared__ uint32_t s_mem[];
+    const uint32_t lds_fixed = 4 * (stack_depth + PT_LANE_SLOTS) * 64 + 4 * PT_SCHED_WORDS;
+    if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + lds_fixed);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;
     stk.base = &s_mem[wave * stack_depth * 64 + lane];
-    float* slot = reinterpret_cast<float*>(&s_mem[4 * stack_depth * 64 + wave * PT_LANE_SLOTS * 64 + lane]);  // slot[k*64]
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t* slot_u = &s_mem[4 * stack_depth * 64 + wave * PT_LANE_SLOTS * 64 + lane];  // slot[k * 64]
+    float* slot = reinterpret_cast<float*>(slot_u);
+    uint32_t* sched = &s_mem[4 * (stack_depth + PT_LANE_SLOTS) * 64 + wave * PT_SCHED_WORDS];
+    if (lane == 0) {
+        sched[PT_SCHED_NEXT] = 0; sched[PT_SCHED_END] = 0;
+        sched[PT_SCHED_ITEM] = PT_NONE; sched[PT_SCHED_REPORT] = PT_NONE;
+    }
 
-    const uint32_t total = counters->n_paths;  // written by k_primary, which ran before on the same stream
     const v3 origin = V3(pp.origin[0], pp.origin[1], pp.origin[2]);
-    const v3 sky = V3(pp.sky[0], pp.sky[1], pp.sky[2]);
-    const uint32_t bounces = pp.bounces, samples = pp.samples;
-    const float ns = (float)samples;
+    const uint32_t bounces = pp.bounces;
+    // (read once: the line that holds n_paths also holds the queue head, which every wave keeps hitting with atomics)
+    const uint32_t total = counters->n_paths;  // written by k_primary, which ran before on the same stream
+    const uint32_t n_heavy = (order_info && pp.n_sweeps > 1u) ? order_info->n_heavy : 0u;
 
     LaneCounters cnt = {0, 0, 0, 0, 0, 0};
     uint32_t lane_rays = 0;
-    unsigned long long t_begin = 0;
-    unsigned long long t_begin_real = 0;
+    unsigned long long t_begin = 0, t_begin_real = 0;
     if (STATS) {
         t_begin = __builtin_amdgcn_s_memtime();
         t_begin_real = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz, the same on every XCD
     }
 
-    uint32_t st = PT_ST_IDLE, pix = 0, sample = 0, bounce = 0, nrays = 0, entry = 0;
+    uint32_t st = PT_ST_IDLE, bounce = 0, nrays = 0;
     Rng rng = {0, 0, 0};
     v3 rpos = origin, rdir = V3(0, 0, 1);
-    v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0), pixel_color = V3(0, 0, 0);
+    v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0);
     HitInfo h;
     h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
-    // wave-uniform scheduling state
-    bool exhausted = false;                  // the work queue has run out
-    uint32_t chunk_next = 0, chunk_end = 0;  // list entries of the current item not handed to lanes yet
-    uint32_t item = PT_NONE;                 // queue item taken but not started: the chunk's previous sweep is still running elsewhere
-    uint32_t cur_chunk = PT_NONE;            // chunk whose sweep this wave has to report as complete (n_sweeps > 1)
-    uint32_t sw_index = 0, sw_begin = 0, sw_end = samples;
-    // Queue: first every chunk once, most expensive first (chunk_order): the n_heavy expensive ones with all their
-    // samples, so that the longest chains of dependent rays start at once and run through; the others with their
-    // first sweep; then sweep after sweep over the others.
-    const uint32_t n_chunks_total = (total + pp.chunk - 1u) / pp.chunk;
-    const uint32_t n_heavy = (order_info && pp.n_sweeps > 1u) ? order_info->n_heavy : 0u;
-    const uint32_t n_light = n_chunks_total - n_heavy;
-    const uint32_t n_items = n_chunks_total + (pp.n_sweeps - 1u) * n_light;
+    bool exhausted = false;  // wave-uniform: the work queue has run out
+    bool waiting = false;    // wave-uniform: holding an item whose chunk is not ready yet
     uint32_t first_entry = 0xFFFFFFFFu, n_chunks = 0;  // STATS only
     unsigned long long item_t0 = 0, item_r0 = 0, worst_cycles = 0, worst_rounds = 0;  // STATS only: the wave's longest item
     uint32_t worst_item = 0, cur_item = 0;
@@ -353,100 +368,128 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
         {
             bool need = st == PT_ST_IDLE;
             unsigned long long m = __ballot(need);
-            if (cur_chunk != PT_NONE && chunk_next == chunk_end && m == ~0ull) {
-                // every pixel of the chunk is parked: publish the sweep once the parking stores have been acknowledged
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&sweeps_done[cur_chunk], sw_index + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cur_chunk = PT_NONE;
-            }
-            if ((uint32_t)__popcll(m) < pp.refill_min) m = 0ull;  // wait until enough lanes are free: newcomers share a tile
-            while (m != 0ull && !exhausted) {
-                if (chunk_next == chunk_end) {
-                    if (item == PT_NONE) {
-                        uint32_t q = 0;
-                        if (lane == 0) q = atomicAdd(&counters->next_path, 1u);
-                        q = __builtin_amdgcn_readfirstlane(q);
-                        if (q >= n_items) {
-                            exhausted = true;
-                            break;
+            if ((uint32_t)__popcll(m) >= pp.refill_min && !exhausted) {  // else: wait until enough lanes are free (newcomers share a tile)
+                // Queue: first every chunk once, most expensive first (chunk_order): the n_heavy expensive ones with
+                // all their samples, so that the longest chains of dependent rays start at once and run through; the
+                // others with their first sweep; then sweep after sweep over the others.
+                const uint32_t n_chunks_total = (total + pp.chunk - 1u) / pp.chunk;
+                const uint32_t n_light = n_chunks_total - n_heavy;
+                const uint32_t n_items = n_chunks_total + (pp.n_sweeps - 1u) * n_light;
+                uint32_t chunk_next = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_NEXT]);
+                uint32_t chunk_end = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_END]);
+                uint32_t report = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_REPORT]);
+                uint32_t sw_begin = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_BEGIN]);
+                uint32_t sw_len = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_LEN]);
+                if (report != PT_NONE && chunk_next == chunk_end && m == ~0ull) {
+                    // every pixel of the chunk is parked: publish the sweep once the parking stores have been acknowledged
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const uint32_t sweep = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_SWEEP]);
+                    if (lane == 0) __hip_atomic_store(&sweeps_done[report], sweep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    report = PT_NONE;
+                }
+                waiting = false;
+                while (m != 0ull) {
+                    if (chunk_next == chunk_end) {
+                        uint32_t item = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_ITEM]);
+                        if (item == PT_NONE) {
+                            uint32_t q = 0;
+                            if (lane == 0) q = atomicAdd(&counters->next_path, 1u);
+                            q = __builtin_amdgcn_readfirstlane(q);
+                            if (q >= n_items) {
+                                exhausted = true;
+                                break;
+                            }
+                            item = q;
                         }
-                        item = q;
+                        uint32_t j = 0, cpos = item;   // sweep, position in the chunk order
+                        if (item >= n_chunks_total) {
+                            const uint32_t r = item - n_chunks_total;
+                            j = 1u + r / n_light;
+                            cpos = n_heavy + (r - (j - 1u) * n_light);
+                        }
+                        const uint32_t c = chunk_order ? chunk_order[cpos] : cpos;
+                        if (j > 0u) {
+                            uint32_t v = 0;
+                            if (lane == 0) v = __hip_atomic_load(&sweeps_done[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            v = __builtin_amdgcn_readfirstlane(v);
+                            if (v < j) {  // not yet: keep the item, run the lanes that have work, ask again next round
+                                if (lane == 0) sched[PT_SCHED_ITEM] = item;
+                                waiting = true;
+                                break;
+                            }
+                            asm volatile("" ::: "memory");
+                        }
+                        if (lane == 0) {
+                            sched[PT_SCHED_ITEM] = PT_NONE;
+                            sched[PT_SCHED_SWEEP] = j;
+                        }
+                        sw_begin = j ? pp.sweep_end[j - 1u] : 0u;
+                        const uint32_t sw_end = (cpos < n_heavy) ? pp.samples : pp.sweep_end[j];
+                        sw_len = (sw_end - sw_begin) | (sw_end >= pp.samples ? 0x80000000u : 0u);
+                        chunk_next = c * pp.chunk;
+                        chunk_end = (total - chunk_next < pp.chunk) ? total : chunk_next + pp.chunk;
+                        if (pp.n_sweeps > 1u && cpos >= n_heavy) report = c;
+                        if (STATS) {
+                            if (n_chunks == 0) first_entry = chunk_next;
+                            const unsigned long long now = __builtin_amdgcn_s_memtime();
+                            if (n_chunks != 0 && now - item_t0 > worst_cycles) { worst_cycles = now - item_t0; worst_rounds = n_rounds - item_r0; worst_item = cur_item; }
+                            item_t0 = now; item_r0 = n_rounds; cur_item = item;
+                            n_chunks++;
+                        }
                     }
-                    uint32_t j = 0, cpos = item;   // sweep, position in the chunk order
-                    if (item >= n_chunks_total) {
-                        const uint32_t r = item - n_chunks_total;
-                        j = 1u + r / n_light;
-                        cpos = n_heavy + (r - (j - 1u) * n_light);
+                    const uint32_t avail = chunk_end - chunk_next;
+                    const uint32_t want = (uint32_t)__popcll(m);
+                    const uint32_t take = want < avail ? want : avail;
+                    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (need && rank < take) {
+                        need = false;
+                        const uint32_t entry = chunk_next + rank;
+                        const PathRec* r = &recs[entry];
+                        const float4 ra = r->a, rb = r->b, rc = r->c, rd = r->d;
+                        h.obj = __float_as_uint(ra.y);
+                        h.u = ra.z; h.v = ra.w;
+                        h.p = V3(rb.x, rb.y, rb.z);
+                        h.n = V3(rb.w, rc.x, rc.y);
+                        rdir = V3(rc.z, rc.w, rd.x);
+                        rng.x = __float_as_uint(rd.y); rng.y = __float_as_uint(rd.z); rng.z = __float_as_uint(rd.w);
+                        slot[(PT_SLOT_HIT + 0) * 64] = ra.y;
+                        slot[(PT_SLOT_HIT + 1) * 64] = h.p.x; slot[(PT_SLOT_HIT + 2) * 64] = h.p.y; slot[(PT_SLOT_HIT + 3) * 64] = h.p.z;
+                        slot[(PT_SLOT_HIT + 4) * 64] = h.n.x; slot[(PT_SLOT_HIT + 5) * 64] = h.n.y; slot[(PT_SLOT_HIT + 6) * 64] = h.n.z;
+                        slot[(PT_SLOT_HIT + 7) * 64] = h.u; slot[(PT_SLOT_HIT + 8) * 64] = h.v;
+                        slot[(PT_SLOT_DIR + 0) * 64] = rdir.x; slot[(PT_SLOT_DIR + 1) * 64] = rdir.y; slot[(PT_SLOT_DIR + 2) * 64] = rdir.z;
+                        nrays = 1;  // the primary ray, traced by k_primary
+                        v3 sum = V3(0, 0, 0);
+                        if (sw_begin != 0u) {  // resume
+                            uint32_t* cw = carry[entry].w;
+                            rng.x = carry_load(cw + 0); rng.y = carry_load(cw + 1); rng.z = carry_load(cw + 2);
+                            nrays = carry_load(cw + 3);
+                            sum = V3(__uint_as_float(carry_load(cw + 4)), __uint_as_float(carry_load(cw + 5)),
+                                     __uint_as_float(carry_load(cw + 6)));
+                        }
+                        slot[(PT_SLOT_SUM + 0) * 64] = sum.x; slot[(PT_SLOT_SUM + 1) * 64] = sum.y; slot[(PT_SLOT_SUM + 2) * 64] = sum.z;
+                        slot_u[PT_SLOT_LEFT * 64] = sw_len & 0x7FFFFFFFu;
+                        slot_u[PT_SLOT_ENTRY * 64] = entry | (sw_len & 0x80000000u);
+                        slot_u[PT_SLOT_PIX * 64] = __float_as_uint(ra.x);
+                        bounce = 0;
+                        ray_color = V3(1, 1, 1);
+                        color = V3(0, 0, 0);
+                        rpos = origin;
+                        st = PT_ST_SHADE;
                     }
-                    const uint32_t c = chunk_order ? chunk_order[cpos] : cpos;
-                    if (j > 0u) {
-                        uint32_t v = 0;
-                        if (lane == 0) v = __hip_atomic_load(&sweeps_done[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v = __builtin_amdgcn_readfirstlane(v);
-                        if (v < j) break;  // not yet: keep the item, run the lanes that have work, ask again next round
-                        asm volatile("" ::: "memory");
-                    }
-                    const uint32_t this_item = item;
-                    (void)this_item;
-                    item = PT_NONE;
-                    sw_index = j;
-                    sw_begin = j ? pp.sweep_end[j - 1u] : 0u;
-                    sw_end = (cpos < n_heavy) ? samples : pp.sweep_end[j];
-                    chunk_next = c * pp.chunk;
-                    chunk_end = (total - chunk_next < pp.chunk) ? total : chunk_next + pp.chunk;
-                    if (pp.n_sweeps > 1u && cpos >= n_heavy) cur_chunk = c;
-                    if (STATS) {
-                        if (n_chunks == 0) first_entry = chunk_next;
-                        const unsigned long long now = __builtin_amdgcn_s_memtime();
-                        if (n_chunks != 0 && now - item_t0 > worst_cycles) { worst_cycles = now - item_t0; worst_rounds = n_rounds - item_r0; worst_item = cur_item; }
-                        item_t0 = now; item_r0 = n_rounds; cur_item = this_item;
-                        n_chunks++;
-                    }
+                    chunk_next += take;
+                    m = __ballot(need);
+                    if (report != PT_NONE && chunk_next == chunk_end) break;  // sweeps: one chunk per wave at a time
                 }
-                const uint32_t avail = chunk_end - chunk_next;
-                const uint32_t want = (uint32_t)__popcll(m);
-                const uint32_t take = want < avail ? want : avail;
-                const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
-                if (need && rank < take) {
-                    need = false;
-                    entry = chunk_next + rank;
-                    const PathRec* r = &recs[entry];
-                    const float4 ra = r->a, rb = r->b, rc = r->c, rd = r->d;
-                    pix = __float_as_uint(ra.x);
-                    h.obj = __float_as_uint(ra.y);
-                    h.u = ra.z; h.v = ra.w;
-                    h.p = V3(rb.x, rb.y, rb.z);
-                    h.n = V3(rb.w, rc.x, rc.y);
-                    rdir = V3(rc.z, rc.w, rd.x);
-                    rng.x = __float_as_uint(rd.y); rng.y = __float_as_uint(rd.z); rng.z = __float_as_uint(rd.w);
-                    slot[0] = ra.y;
-                    slot[1 * 64] = h.p.x; slot[2 * 64] = h.p.y; slot[3 * 64] = h.p.z;
-                    slot[4 * 64] = h.n.x; slot[5 * 64] = h.n.y; slot[6 * 64] = h.n.z;
-                    slot[7 * 64] = h.u; slot[8 * 64] = h.v;
-                    slot[9 * 64] = rdir.x; slot[10 * 64] = rdir.y; slot[11 * 64] = rdir.z;
-                    sample = sw_begin; bounce = 0;
-                    nrays = 1;  // the primary ray, traced by k_primary
-                    pixel_color = V3(0, 0, 0);
-                    if (sw_begin != 0u) {  // resume
-                        uint32_t* cw = carry[entry].w;
-                        rng.x = carry_load(cw + 0); rng.y = carry_load(cw + 1); rng.z = carry_load(cw + 2);
-                        nrays = carry_load(cw + 3);
-                        pixel_color = V3(__uint_as_float(carry_load(cw + 4)), __uint_as_float(carry_load(cw + 5)),
-                                         __uint_as_float(carry_load(cw + 6)));
-                    }
-                    ray_color = V3(1, 1, 1);
-                    color = V3(0, 0, 0);
-                    rpos = origin;
-                    st = PT_ST_SHADE;
+                if (lane == 0) {
+                    sched[PT_SCHED_NEXT] = chunk_next; sched[PT_SCHED_END] = chunk_end;
+                    sched[PT_SCHED_REPORT] = report;
+                    sched[PT_SCHED_BEGIN] = sw_begin; sched[PT_SCHED_LEN] = sw_len;
                 }
-                chunk_next += take;
-                m = __ballot(need);
-                if (cur_chunk != PT_NONE && chunk_next == chunk_end) break;  // sweeps: one chunk per wave at a time
             }
         }
         if (!__any(st != PT_ST_IDLE)) {
             if (exhausted) break;
-            if (item != PT_NONE) __builtin_amdgcn_s_sleep(16);
+            if (waiting) __builtin_amdgcn_s_sleep(16);
             continue;
         }
 
@@ -455,34 +498,39 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
         // A path that stops moves on to the pixel's next sample, whose first hit is the cached primary hit.
         // Returns false when the lane has run the last sample of its sweep.
         auto next_sample = [&]() -> bool {
-            pixel_color = add3(pixel_color, color);
-            sample++;
-            if (sample >= sw_end) {
-                if (sw_end >= samples) {
-                    out[pix] = make_float4(pt_div(pixel_color.x, ns), pt_div(pixel_color.y, ns), pt_div(pixel_color.z, ns), 1.0f);
+            const v3 sum = add3(V3(slot[(PT_SLOT_SUM + 0) * 64], slot[(PT_SLOT_SUM + 1) * 64], slot[(PT_SLOT_SUM + 2) * 64]), color);
+            const uint32_t left = slot_u[PT_SLOT_LEFT * 64] - 1u;
+            if (left == 0u) {
+                const uint32_t e = slot_u[PT_SLOT_ENTRY * 64];
+                if (e & 0x80000000u) {
+                    const uint32_t pix = slot_u[PT_SLOT_PIX * 64];
+                    const float ns = (float)pp.samples;
+                    out[pix] = make_float4(pt_div(sum.x, ns), pt_div(sum.y, ns), pt_div(sum.z, ns), 1.0f);
                     // queries the reference would have run: it re-traces the primary ray for every sample
-                    aux_rays[pix] = nrays + samples - 1u;
+                    aux_rays[pix] = nrays + pp.samples - 1u;
                 } else {
                     // park the pixel until its next sweep
-                    uint32_t* cw = carry[entry].w;
+                    uint32_t* cw = carry[e].w;
                     carry_store(cw + 0, rng.x); carry_store(cw + 1, rng.y); carry_store(cw + 2, rng.z);
                     carry_store(cw + 3, nrays);
-                    carry_store(cw + 4, __float_as_uint(pixel_color.x)); carry_store(cw + 5, __float_as_uint(pixel_color.y));
-                    carry_store(cw + 6, __float_as_uint(pixel_color.z));
+                    carry_store(cw + 4, __float_as_uint(sum.x)); carry_store(cw + 5, __float_as_uint(sum.y));
+                    carry_store(cw + 6, __float_as_uint(sum.z));
                 }
                 st = PT_ST_IDLE;
                 return false;
             }
+            slot[(PT_SLOT_SUM + 0) * 64] = sum.x; slot[(PT_SLOT_SUM + 1) * 64] = sum.y; slot[(PT_SLOT_SUM + 2) * 64] = sum.z;
+            slot_u[PT_SLOT_LEFT * 64] = left;
             bounce = 0;
             rpos = origin;
-            rdir = V3(slot[9 * 64], slot[10 * 64], slot[11 * 64]);
+            rdir = V3(slot[(PT_SLOT_DIR + 0) * 64], slot[(PT_SLOT_DIR + 1) * 64], slot[(PT_SLOT_DIR + 2) * 64]);
             ray_color = V3(1, 1, 1);
             color = V3(0, 0, 0);
-            h.obj = __float_as_uint(slot[0]);
-            h.p = V3(slot[1 * 64], slot[2 * 64], slot[3 * 64]);
-            h.n = V3(slot[4 * 64], slot[5 * 64], slot[6 * 64]);
-            h.u = slot[7 * 64];
-            h.v = slot[8 * 64];
+            h.obj = slot_u[(PT_SLOT_HIT + 0) * 64];
+            h.p = V3(slot[(PT_SLOT_HIT + 1) * 64], slot[(PT_SLOT_HIT + 2) * 64], slot[(PT_SLOT_HIT + 3) * 64]);
+            h.n = V3(slot[(PT_SLOT_HIT + 4) * 64], slot[(PT_SLOT_HIT + 5) * 64], slot[(PT_SLOT_HIT + 6) * 64]);
+            h.u = slot[(PT_SLOT_HIT + 7) * 64];
+            h.v = slot[(PT_SLOT_HIT + 8) * 64];
             return true;
         };
         // what the surface emits, and whether the path stops on it (black albedo)
@@ -505,8 +553,8 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 if (h.obj != PT_NONE) {
                     stop = add_emitted();
                 } else {
-                    color = V3(pt_fma(ray_color.x, sky.x, color.x), pt_fma(ray_color.y, sky.y, color.y),
-                               pt_fma(ray_color.z, sky.z, color.z));
+                    color = V3(pt_fma(ray_color.x, pp.sky[0], color.x), pt_fma(ray_color.y, pp.sky[1], color.y),
+                               pt_fma(ray_color.z, pp.sky[2], color.z));
                     stop = true;
                 }
                 if (stop) {

@@ -216,6 +216,36 @@ def test_million_triangles_tlas_vs_loop_and_oracle_crop():
     assert (full["primary_object"] != abi.PT_U32_MAX).mean() > 0.3
 
 
+@pytest.mark.parametrize("name,spp", [("cornell", 32), ("boxes", 32), ("instanced_boxes", 8)])
+def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
+    """The order in which k_paths takes the pixels (sample sweeps, cost hints from the previous frame, whole-chunk
+    or per-lane refill) never shows in a result: repeated frames of one context and contexts with other schedules
+    all reproduce the golden frame bit for bit."""
+    scene, _ = golden_scenes()[name]
+    scene.samples = spp
+    frame = scene.frame()
+    ref = oracle_render(scene, frame)
+    want = (ref["image"], ref["primary_object"], ref["primary_flat_id"], ref["primary_t"].view(np.uint32), ref["ray_count"])
+
+    def run(n_frames):
+        with abi.Context() as ctx:
+            ctx.upload_scene(scene)
+            for _ in range(n_frames):   # from the second frame on the previous frame's ray counts order the work
+                img = ctx.render(frame)
+                got = dict(image=img, primary_object=ctx.read_aux(abi.PT_AUX_PRIMARY_OBJECT),
+                           primary_flat_id=ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID), primary_t=ctx.read_aux(abi.PT_AUX_PRIMARY_T),
+                           ray_count=ctx.read_aux(abi.PT_AUX_RAY_COUNT), accel=ctx.check_accel())
+                assert_same(got, *want)
+
+    run(3)
+    for env in ({"PT_AMD_SWEEPS": "1"}, {"PT_AMD_SWEEPS": "8"}, {"PT_AMD_NO_COST_HINTS": "1"}, {"PT_AMD_REFILL_MIN": "1"},
+                {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            run(2)
+
+
 def test_partition_union_equals_full_frame():
     scene = scenes.boxes(200, 120, 4, 10)
     full = render_all(scene, scene.frame())

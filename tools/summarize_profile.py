@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 output of tools/profile.sh into profiles/<tag>_summary.json (+ kernel stats CSV copy).
 
-    python tools/summarize_profile.py <tag> [--kernel k_render] [--workload boxes]
+    python tools/summarize_profile.py <tag> [--kernel k_paths] [--workload boxes]
 
 Per-launch averages over the dispatches of the chosen kernel:
   duration from --kernel-trace; SQ counters; HBM traffic from FETCH_SIZE / WRITE_SIZE with the gfx950
@@ -13,11 +13,17 @@ import argparse
 import csv
 import glob
 import json
+import re
 import shutil
 from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+
+
+def is_stats_variant(name):
+    """k_primary<MODE, true> / k_paths<MODE, true>: the instrumented builds used for the work counters."""
+    return re.search(r"<\d+, true>", name.split("(")[0]) is not None
 
 
 def read_counters(d, kernel):
@@ -26,7 +32,7 @@ def read_counters(d, kernel):
     for f in files:
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if kernel in row["Kernel_Name"] and "true>" not in row["Kernel_Name"].split("(")[0].replace("false, true", "true>"):
+                if kernel in row["Kernel_Name"] and not is_stats_variant(row["Kernel_Name"]):
                     per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
     return {c: (sum(v.values()) / len(v), len(v)) for c, v in per.items()}
 
@@ -34,7 +40,7 @@ def read_counters(d, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--kernel", default="k_render")
+    ap.add_argument("--kernel", default="k_paths")
     ap.add_argument("--workload", default="boxes")
     args = ap.parse_args()
     src = ROOT / "gpurun_out" / f"prof_{args.tag}"
@@ -50,7 +56,7 @@ def main():
         out["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                 "pct": float(r["Percentage"])} for r in rows[:8]]
         for r in rows:
-            if args.kernel in r["Name"] and "<false, true>" not in r["Name"] and "<true, true>" not in r["Name"]:
+            if args.kernel in r["Name"] and not is_stats_variant(r["Name"]):
                 out["avg_kernel_ms"] = float(r["AverageNs"]) / 1e6
                 out["calls"] = int(r["Calls"])
                 break
@@ -58,7 +64,7 @@ def main():
     if trace:
         with open(trace[0]) as fh:
             for r in csv.DictReader(fh):
-                if args.kernel in r["Kernel_Name"]:
+                if args.kernel in r["Kernel_Name"] and not is_stats_variant(r["Kernel_Name"]):
                     out["launch"] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
                                                        "Workgroup_Size_X", "Grid_Size_X")}
                     break
