@@ -33,13 +33,23 @@ static_assert(sizeof(PathRec) == 64, "PathRec");
 
 // State of a pixel parked between two sweeps, one per list entry: rng x y z, rays so far, radiance sum x y z, 0.
 // Written by one workgroup and read by another (possibly on another XCD, whose L2 is not coherent with the
-// writer's) inside one launch, so it only moves through device-scope atomic loads and stores, which bypass the
-// non-coherent cache levels; the chunk's flag is published after the stores have been acknowledged.
+// writer's) inside one launch, so it only moves through loads and stores that bypass the non-coherent cache
+// levels; the chunk's flag is published after the stores have been acknowledged.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct PathCarry {
-    uint32_t w[8];
+    u32x4 lo, hi;
 };
-PT_DEV void carry_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-PT_DEV uint32_t carry_load(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static_assert(sizeof(PathCarry) == 32, "PathCarry");
+// 16-byte accesses that go past the non-coherent cache levels (sc0 sc1: system scope), like device-scope atomic
+// loads and stores of a dword do; the load waits for its data.
+PT_DEV void carry_store(PathCarry* p, u32x4 lo, u32x4 hi) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1"
+                 :: "v"(p), "v"(lo), "v"(hi) : "memory");
+}
+PT_DEV void carry_load(const PathCarry* p, u32x4& lo, u32x4& hi) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
+}
 
 struct PathParams {
     float origin[3];
@@ -460,11 +470,11 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                         nrays = 1;  // the primary ray, traced by k_primary
                         v3 sum = V3(0, 0, 0);
                         if (sw_begin != 0u) {  // resume
-                            uint32_t* cw = carry[entry].w;
-                            rng.x = carry_load(cw + 0); rng.y = carry_load(cw + 1); rng.z = carry_load(cw + 2);
-                            nrays = carry_load(cw + 3);
-                            sum = V3(__uint_as_float(carry_load(cw + 4)), __uint_as_float(carry_load(cw + 5)),
-                                     __uint_as_float(carry_load(cw + 6)));
+                            u32x4 lo, hi;
+                            carry_load(&carry[entry], lo, hi);
+                            rng.x = lo.x; rng.y = lo.y; rng.z = lo.z;
+                            nrays = lo.w;
+                            sum = V3(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z));
                         }
                         slot[(PT_SLOT_SUM + 0) * 64] = sum.x; slot[(PT_SLOT_SUM + 1) * 64] = sum.y; slot[(PT_SLOT_SUM + 2) * 64] = sum.z;
                         slot_u[PT_SLOT_LEFT * 64] = sw_len & 0x7FFFFFFFu;
@@ -510,11 +520,10 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                     aux_rays[pix] = nrays + pp.samples - 1u;
                 } else {
                     // park the pixel until its next sweep
-                    uint32_t* cw = carry[e].w;
-                    carry_store(cw + 0, rng.x); carry_store(cw + 1, rng.y); carry_store(cw + 2, rng.z);
-                    carry_store(cw + 3, nrays);
-                    carry_store(cw + 4, __float_as_uint(sum.x)); carry_store(cw + 5, __float_as_uint(sum.y));
-                    carry_store(cw + 6, __float_as_uint(sum.z));
+                    u32x4 lo, hi;
+                    lo.x = rng.x; lo.y = rng.y; lo.z = rng.z; lo.w = nrays;
+                    hi.x = __float_as_uint(sum.x); hi.y = __float_as_uint(sum.y); hi.z = __float_as_uint(sum.z); hi.w = 0u;
+                    carry_store(&carry[e], lo, hi);
                 }
                 st = PT_ST_IDLE;
                 return false;
