@@ -273,6 +273,7 @@ typedef struct PtStats {
     uint32_t wave_life_hist[32];                  /* ... histogram, 2^19 cycles per bucket              */
     /* detail only: the part of xforms / box_tests / tri_tests / hits done by the primary pass */
     uint64_t primary_xforms, primary_box_tests, primary_tri_tests, primary_hits;
+    uint64_t object_passes; /* detail only: times a k_paths wave ran the per-object test for its lanes' candidates */
 } PtStats;
 
 /* detail != 0 re-runs nothing; it only selects whether the next renders also

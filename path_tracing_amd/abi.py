@@ -85,7 +85,7 @@ class PtStats(C.Structure):
                 ("wave_life_sum", C.c_uint64), ("wave_life_max", C.c_uint64), ("waves", C.c_uint64),
                 ("wave_life_hist", C.c_uint32 * 32),
                 ("primary_xforms", C.c_uint64), ("primary_box_tests", C.c_uint64), ("primary_tri_tests", C.c_uint64),
-                ("primary_hits", C.c_uint64)]
+                ("primary_hits", C.c_uint64), ("object_passes", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "wave_life_hist" else getattr(self, n)) for n, _ in self._fields_}

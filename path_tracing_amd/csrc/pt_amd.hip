@@ -85,7 +85,7 @@ struct pt_ctx {
     uint32_t chunk_pixels = 64;   // see PathParams::chunk
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
     uint32_t wave_log_records = 0;
-    uint32_t max_sweeps = 5;      // see PathParams::n_sweeps
+    uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
     bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
     FrameKey hint_key;
@@ -577,6 +577,7 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.cycles_shade = c.cyc_shade;
     ctx->stats.wave_rounds = c.rounds;
     ctx->stats.lane_rounds = c.lane_rounds;
+    ctx->stats.object_passes = c.passes;
     ctx->stats.wave_life_sum = c.wave_life_sum;
     ctx->stats.wave_life_max = c.wave_life_max;
     ctx->stats.waves = c.waves;

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     uint32_t first_entry = 0xFFFFFFFFu, n_chunks = 0;  // STATS only
     unsigned long long item_t0 = 0, item_r0 = 0, worst_cycles = 0, worst_rounds = 0;  // STATS only: the wave's longest item
     uint32_t worst_item = 0, cur_item = 0;
-    unsigned long long cyc_refill = 0, cyc_trace = 0, cyc_shade = 0, n_rounds = 0, lane_rounds = 0;  // STATS only
+    unsigned long long cyc_refill = 0, cyc_trace = 0, cyc_shade = 0, n_rounds = 0, lane_rounds = 0, n_passes = 0;  // STATS only
 
     for (;;) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -607,6 +607,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             Best b;
             cnt.passes = 0;
             closest_hit<MODE, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
+            if (STATS) n_passes += cnt.passes;
             // waves whose rays are expensive (many candidate objects) are the critical path of the launch: let them issue first
             if (cnt.passes >= PT_WAVE_PRIO_PASSES) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             atomicAdd(&counters->cyc_trace, cyc_trace);
             atomicAdd(&counters->cyc_shade, cyc_shade);
             atomicAdd(&counters->rounds, n_rounds);
+            atomicAdd(&counters->passes, n_passes);
             atomicAdd(&counters->lane_rounds, lane_rounds);
             atomicAdd(&counters->hits, (unsigned long long)e);
             atomicAdd(&counters->xforms, (unsigned long long)a);

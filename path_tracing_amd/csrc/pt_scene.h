@@ -146,8 +146,7 @@ struct DCounters {
     unsigned long long hits;
     unsigned int n_paths;      // entries k_primary appended to the path list
     unsigned int next_path;    // work queue head of k_paths: next unassigned list entry
-    unsigned int _pad1;
-    unsigned int _pad0;
+    unsigned long long passes;   // object-test passes of k_paths waves (STATS only)
     // phase clocks of the frame kernel (shader cycles summed over waves), STATS variant only
     unsigned long long cyc_refill, cyc_trace, cyc_shade, rounds, lane_rounds, wave_life_sum, wave_life_max, waves;
     unsigned int life_hist[32];   // histogram of k_paths wave lifetimes, 2^19 cycles per bucket (STATS only)
