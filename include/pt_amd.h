@@ -194,8 +194,10 @@ int pt_upload_materials(pt_ctx* ctx,
                         const float* texture_data, uint32_t n_texture_data);
 
 /* Replaces the per-frame `objects.write_buffer` of extract_visible
- * (reference src/extract.rs:337-342); rebuilds the TLAS. The reference's
- * `emissives` buffer is bound but never read by the shader and is not taken. */
+ * (reference src/extract.rs:337-342); rebuilds the TLAS, or, when the number of
+ * objects is unchanged, refits its boxes (the image does not depend on which).
+ * The reference's `emissives` buffer is bound but never read by the shader and
+ * is not taken. */
 int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects);
 
 /* ---- render ---------------------------------------------------------------- */
@@ -265,7 +267,8 @@ typedef struct PtStats {
     double paths_ms;        /* and the path pass (k_paths)                      */
     double build_ms;        /* device time of the last TLAS build                */
     uint32_t trace_launches;/* kernel launches that trace_ms covers              */
-    uint32_t accel_used;    /* bit 0: TLAS traversal, bit 1: BLAS traversal      */
+    uint32_t accel_used;    /* bit 0: TLAS traversal, bit 1: BLAS traversal,
+                               bit 2: the last object upload refitted the TLAS   */
     /* detail only: shader cycles summed over waves spent handing out pixels, in
      * closest hit, and in shading; rounds of the wave loop; lanes tracing per round */
     uint64_t cycles_refill, cycles_trace, cycles_shade, wave_rounds, lane_rounds;

@@ -23,7 +23,8 @@ namespace {
 
 constexpr uint32_t kBlasMinTris = 16;   // PT_ACCEL_AUTO: meshes with more triangles than this get a BLAS
 constexpr uint32_t kTlasMinObjects = 12; // PT_ACCEL_AUTO: scenes with more objects than this get a TLAS
-constexpr uint32_t kMaxStackDepth = 96;  // LDS: 4 waves * depth * 256 B per workgroup
+constexpr uint32_t kMaxStackDepth = 96;
+constexpr uint32_t kTlasMaxRefits = 15;  // object uploads that may refit the TLAS before it is built afresh  // LDS: 4 waves * depth * 256 B per workgroup
 
 thread_local std::string g_create_error;
 
@@ -69,7 +70,7 @@ struct pt_ctx {
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors;
     // frame outputs
-    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_counters_k1, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
+    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_counters_k1, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
@@ -86,6 +87,10 @@ struct pt_ctx {
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
     uint32_t wave_log_records = 0;
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
+    bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
+    uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
+    uint32_t tlas_refits = 0;     // refits since that build
+    bool tlas_refitted = false;   // the last object upload refitted
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
     bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
     FrameKey hint_key;
@@ -188,6 +193,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         ctx->n_cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
         if (const char* e = std::getenv("PT_AMD_REFILL_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_min = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
+        if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; }
         std::snprintf(ctx->info, sizeof ctx->info, "pt_amd abi %d | %s %s | %d CUs | %d MHz | %.0f GiB", PT_ABI_VERSION, prop.name,
@@ -225,7 +231,7 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
-                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_counters_k1, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
+                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_counters_k1, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -478,15 +484,40 @@ int rebuild_objects(pt_ctx* ctx) {
     PT_HIP(ctx, hipGetLastError());
     const bool want_tlas = (ctx->cfg.accel == PT_ACCEL_BVH) || (ctx->cfg.accel == PT_ACCEL_AUTO && n > kTlasMinObjects);
     uint32_t depth = 0;
+    bool refitted = false;
+    if (!want_tlas || n < 2) ctx->tlas_built_n = 0;
     if (want_tlas) {
         if (n == 1) {
             ctx->tlas_root = PT_LEAF_BIT | 0u;
         } else {
-            PT_HIP(ctx, ctx->d_tlas_nodes.ensure(sizeof(BvhNode) * (size_t)(n - 1)));
             uint32_t* slot = ctx->t_info.as<uint32_t>() + ctx->n_meshes;
             PT_HIP(ctx, hipMemsetAsync(slot, 0, sizeof(uint32_t), s));
-            int rc = build_lbvh(ctx, ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_nodes.as<BvhNode>(), 0, slot);
-            if (rc != PT_OK) return rc;
+            const size_t nb = sizeof(uint32_t) * (size_t)n;
+            // Same number of objects as the tree was built for: keep its topology (leaf order and parent links) and
+            // only fit the boxes again, bottom-up. Any valid tree gives the same image; a stale topology only costs
+            // traversal steps, so a fresh build is made every kTlasMaxRefits updates.
+            if (ctx->allow_refit && ctx->tlas_built_n == n && ctx->tlas_refits < kTlasMaxRefits) {
+                PT_HIP(ctx, ctx->t_arrive.ensure(nb));
+                PT_HIP(ctx, hipMemsetAsync(ctx->t_arrive.p, 0, nb, s));
+                k_fit<<<div_up(n, 256), 256, 0, s>>>(ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, ctx->d_tlas_order.as<uint32_t>(), n,
+                                                     ctx->d_tlas_par_int.as<uint32_t>(), ctx->d_tlas_par_leaf.as<uint32_t>(),
+                                                     ctx->t_arrive.as<uint32_t>(), ctx->d_tlas_nodes.as<BvhNode>(), 0, slot);
+                PT_HIP(ctx, hipGetLastError());
+                ctx->tlas_refits++;
+                refitted = true;
+            } else {
+                PT_HIP(ctx, ctx->d_tlas_nodes.ensure(sizeof(BvhNode) * (size_t)(n - 1)));
+                int rc = build_lbvh(ctx, ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_nodes.as<BvhNode>(), 0, slot);
+                if (rc != PT_OK) return rc;
+                PT_HIP(ctx, ctx->d_tlas_order.ensure(nb));
+                PT_HIP(ctx, ctx->d_tlas_par_int.ensure(nb));
+                PT_HIP(ctx, ctx->d_tlas_par_leaf.ensure(nb));
+                PT_HIP(ctx, hipMemcpyAsync(ctx->d_tlas_order.p, ctx->t_vals0.p, nb, hipMemcpyDeviceToDevice, s));
+                PT_HIP(ctx, hipMemcpyAsync(ctx->d_tlas_par_int.p, ctx->t_par_int.p, nb, hipMemcpyDeviceToDevice, s));
+                PT_HIP(ctx, hipMemcpyAsync(ctx->d_tlas_par_leaf.p, ctx->t_par_leaf.p, nb, hipMemcpyDeviceToDevice, s));
+                ctx->tlas_built_n = n;
+                ctx->tlas_refits = 0;
+            }
             PT_HIP(ctx, hipMemcpyAsync(&depth, slot, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             ctx->tlas_root = 0;
         }
@@ -497,6 +528,7 @@ int rebuild_objects(pt_ctx* ctx) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, ctx->evb0, ctx->evb1) == hipSuccess) ctx->stats.build_ms = ms;
     ctx->tlas_depth = depth;
+    ctx->tlas_refitted = refitted;
     return PT_OK;
 }
 
@@ -584,7 +616,7 @@ int finish_timing(pt_ctx* ctx) {
     for (int k = 0; k < 32; ++k) ctx->stats.wave_life_hist[k] = c.life_hist[k];
     ctx->stats.paths = ctx->last_paths;
     ctx->stats.rays_reference = c.rays + ctx->last_primary_traced + ctx->last_primary;
-    ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u);
+    ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u) | (ctx->tlas_refitted ? 4u : 0u);
     ctx->timing_pending = false;
     return PT_OK;
 }

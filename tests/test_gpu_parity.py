@@ -362,6 +362,34 @@ def test_error_codes():
         assert np.isfinite(img).all()
 
 
+def test_object_update_refits_tlas_with_identical_results():
+    """pt_upload_objects with an unchanged object count keeps the TLAS topology and refits its boxes (the per-frame
+    update of extract_visible, reference src/extract.rs:297-346). The image must not depend on it."""
+    a = scenes.instanced_boxes(n_objects=600, width=96, height=64, samples=2, extent=6.0)
+    b = scenes.instanced_boxes(n_objects=600, width=96, height=64, samples=2, extent=6.0, seed=1234)   # every object somewhere else
+    frame = a.frame()
+    fresh = render_all(b, frame)
+    assert not fresh["stats"]["accel_used"] & 4
+    with abi.Context() as ctx:
+        ctx.upload_scene(a)
+        ctx.render(frame)
+        for k in range(3):      # refit, refit, refit
+            ctx.upload_objects(b.objects if k % 2 == 0 else a.objects)
+        ctx.upload_materials(b.materials, b.textures, b.texture_data)   # the two scenes draw different material colours
+        ctx.upload_objects(b.objects)
+        img = ctx.render(frame)
+        st = ctx.stats()
+        assert st["accel_used"] & 1 and st["accel_used"] & 4, "expected a refitted TLAS"
+        assert ctx.check_accel()["errors"] == 0
+        assert np.array_equal(img.view(np.uint32), fresh["image"].view(np.uint32))
+        assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID), fresh["primary_flat_id"])
+        assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), fresh["ray_count"])
+        # a different object count builds afresh
+        ctx.upload_objects(b.objects[:500])
+        ctx.render(frame)
+        assert not ctx.stats()["accel_used"] & 4
+
+
 def test_reupload_order_independent():
     scene = scenes.boxes(64, 36, 2, 4)
     ref = render_all(scene, scene.frame())
