@@ -115,6 +115,10 @@ typedef struct PtSettings {
 #define PT_FRAME_ACCUMULATE 0x1u /* add this frame into the context's radiance
                                     accumulation buffer and return the mean   */
 #define PT_FRAME_RESET      0x2u /* clear the accumulation buffer first        */
+#define PT_FRAME_OUTPUT_F16 0x4u /* the image is written as RGBA binary16 (8
+                                    bytes per pixel, round to nearest even), the
+                                    format of the reference's render target
+                                    (src/shader.rs:321), instead of RGBA f32    */
 
 /*
  * The subset of Bevy's `View` and `Globals` uniforms the shader reads
@@ -203,17 +207,25 @@ int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects);
 /* ---- render ---------------------------------------------------------------- */
 
 /* Replaces the body of RayTraceNode::run (reference src/shader.rs:121-213):
- * traces the frame and copies width*height RGBA f32 (row 0 = top, A = 1) to
- * `out_rgba_host`. Synchronous. */
-int pt_render(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_host);
+ * traces the frame and copies width*height RGBA pixels (row 0 = top, A = 1;
+ * f32, or binary16 with PT_FRAME_OUTPUT_F16) to `out_rgba_host`. Synchronous. */
+int pt_render(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_host);
 
 /* Same, but the image is written to device memory of the context's device and
  * the call returns after enqueueing on `hip_stream` (a hipStream_t, or NULL for
  * the context's own stream, in which case the call synchronises before
  * returning). Used by callers that keep the image on the GPU (multi-GPU
  * reduce/gather, on-device post-processing). */
-int pt_render_device(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_device,
+int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
                      void* hip_stream);
+
+/* Page-locked host memory owned by the context, for the image pt_render returns
+ * (and for the arrays handed to pt_upload_*): copies to and from it run at the
+ * PCIe rate, about three times the rate of pageable memory on the test machine.
+ * Freed by pt_host_free or pt_destroy. No counterpart in the reference (wgpu's
+ * staging buffers play this role there). */
+int pt_host_alloc(pt_ctx* ctx, size_t bytes, void** out_ptr);
+int pt_host_free(pt_ctx* ctx, void* ptr);
 
 /* ---- closest-hit query (the query.wgsl entry point on its own) -------------- */
 

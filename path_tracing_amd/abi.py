@@ -30,6 +30,7 @@ PT_ERR_NO_DEVICE = -7
 
 PT_FRAME_ACCUMULATE = 0x1
 PT_FRAME_RESET = 0x2
+PT_FRAME_OUTPUT_F16 = 0x4
 
 PT_ACCEL_AUTO, PT_ACCEL_BRUTE, PT_ACCEL_BVH = 0, 1, 2
 PT_TIE_REFERENCE, PT_TIE_LOWEST = 0, 1
@@ -96,7 +97,7 @@ assert C.sizeof(PtSettings) == 32 and C.sizeof(PtFrame) == 192 and C.sizeof(PtCo
 # every symbol include/pt_amd.h declares
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_upload_materials",
            "pt_upload_objects", "pt_render", "pt_render_device", "pt_query", "pt_read_aux",
-           "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log"]
+           "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log", "pt_host_alloc", "pt_host_free"]
 
 LIB_NAME = "libpt_amd.so"
 
@@ -138,6 +139,8 @@ def load_library():
     lib.pt_device_info.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.pt_debug_check_accel.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pt_debug_wave_log.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32)]
+    lib.pt_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.pt_host_free.argtypes = [vp, vp]
     for name in EXPORTS:
         if name != "pt_last_error":
             getattr(lib, name).restype = C.c_int
@@ -236,8 +239,23 @@ class Context:
         self.upload_materials(scene.materials, scene.textures, scene.texture_data)
         self.upload_objects(scene.objects)
 
-    def render(self, frame: PtFrame) -> np.ndarray:
-        out = np.empty((frame.height, frame.width, 4), dtype=np.float32)
+    def host_array(self, shape, dtype) -> np.ndarray:
+        """A numpy array over page-locked memory owned by the context (valid until close()): the staging buffer to
+        pass as `out=` to render() frame after frame."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.pt_host_alloc(self._h, max(n, 1), C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def render(self, frame: PtFrame, out: np.ndarray | None = None) -> np.ndarray:
+        """One frame into a host array (a new one, or `out` when the caller keeps a staging buffer across frames)."""
+        dt = np.float16 if frame.flags & PT_FRAME_OUTPUT_F16 else np.float32
+        if out is None:
+            out = np.empty((frame.height, frame.width, 4), dtype=dt)
+        if out.dtype != dt or out.shape != (frame.height, frame.width, 4) or not out.flags.c_contiguous:
+            raise ValueError("render: `out` must be a C-contiguous (height, width, 4) array of the frame's output type")
         self._check(self._lib.pt_render(self._h, C.byref(frame), _ptr(out) if out.size else None))
         self.size = (frame.height, frame.width)
         return out

@@ -70,7 +70,7 @@ struct pt_ctx {
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors;
     // frame outputs
-    DevBuf d_out, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_counters_k1, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
+    DevBuf d_out, d_out16, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_counters_k1, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
@@ -87,6 +87,7 @@ struct pt_ctx {
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
     uint32_t wave_log_records = 0;
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
+    std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
     uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
     uint32_t tlas_refits = 0;     // refits since that build
@@ -230,9 +231,10 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->d_obj_hi, &ctx->d_tlas_nodes, &ctx->d_tri_base, &ctx->d_materials, &ctx->d_textures,
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
-                      &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
+                      &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_out16, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
                       &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_counters_k1, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
     for (DevBuf* b : bufs) b->release();
+    for (void* p : ctx->host_allocs) (void)hipHostFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evm) (void)hipEventDestroy(ctx->evm);
@@ -859,14 +861,23 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
 
 extern "C" {
 
-int pt_render_device(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_device, void* hip_stream) {
+int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device, void* hip_stream) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
         if (!frame || !out_rgba_device) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_device: null argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
         hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
-        int rc = render_enqueue(ctx, frame, out_rgba_device, s);
-        if (rc != PT_OK) return rc;
+        if (frame->flags & PT_FRAME_OUTPUT_F16) {
+            const size_t n_pix = (size_t)frame->width * frame->height;
+            PT_HIP(ctx, ctx->d_out.ensure(16 * n_pix));
+            int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), s);
+            if (rc != PT_OK) return rc;
+            k_pack_f16<<<div_up((uint32_t)n_pix, 256), 256, 0, s>>>(ctx->d_out.as<float4>(), reinterpret_cast<uint2*>(out_rgba_device), (uint32_t)n_pix);
+            PT_HIP(ctx, hipGetLastError());
+        } else {
+            int rc = render_enqueue(ctx, frame, reinterpret_cast<float*>(out_rgba_device), s);
+            if (rc != PT_OK) return rc;
+        }
         if (!hip_stream) PT_HIP(ctx, hipStreamSynchronize(s));
         return PT_OK;
     } catch (...) {
@@ -874,21 +885,57 @@ int pt_render_device(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_device, 
     }
 }
 
-int pt_render(pt_ctx* ctx, const PtFrame* frame, float* out_rgba_host) {
+int pt_render(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_host) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
         if (!frame || !out_rgba_host) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: null argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
-        const size_t bytes = (size_t)16 * frame->width * frame->height;
-        PT_HIP(ctx, ctx->d_out.ensure(bytes));
+        const size_t n_pix = (size_t)frame->width * frame->height;
+        const bool f16 = (frame->flags & PT_FRAME_OUTPUT_F16) != 0;
+        const size_t out_bytes = (f16 ? 8 : 16) * n_pix;
+        PT_HIP(ctx, ctx->d_out.ensure(16 * n_pix));
         int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), ctx->stream);
         if (rc != PT_OK) return rc;
-        PT_HIP(ctx, hipMemcpyAsync(out_rgba_host, ctx->d_out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        const void* src = ctx->d_out.p;
+        if (f16 && n_pix) {
+            PT_HIP(ctx, ctx->d_out16.ensure(8 * n_pix));
+            k_pack_f16<<<div_up((uint32_t)n_pix, 256), 256, 0, ctx->stream>>>(ctx->d_out.as<float4>(), ctx->d_out16.as<uint2>(), (uint32_t)n_pix);
+            PT_HIP(ctx, hipGetLastError());
+            src = ctx->d_out16.p;
+        }
+        PT_HIP(ctx, hipMemcpyAsync(out_rgba_host, src, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return PT_OK;
     } catch (...) {
         return fail(ctx, PT_ERR_DEVICE, "pt_render: unexpected exception");
     }
+}
+
+int pt_host_alloc(pt_ctx* ctx, size_t bytes, void** out_ptr) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!out_ptr || bytes == 0) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_host_alloc: null pointer or zero size");
+        *out_ptr = nullptr;
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        void* p = nullptr;
+        PT_HIP(ctx, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        ctx->host_allocs.push_back(p);
+        *out_ptr = p;
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_OUT_OF_MEMORY, "pt_host_alloc: host allocation failed");
+    }
+}
+
+int pt_host_free(pt_ctx* ctx, void* ptr) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    if (!ptr) return PT_OK;
+    auto it = std::find(ctx->host_allocs.begin(), ctx->host_allocs.end(), ptr);
+    if (it == ctx->host_allocs.end()) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_host_free: not a pointer from pt_host_alloc of this context");
+    ctx->host_allocs.erase(it);
+    (void)hipSetDevice(ctx->device);
+    PT_HIP(ctx, hipHostFree(ptr));
+    return PT_OK;
 }
 
 int pt_query(pt_ctx* ctx, const PtRay* rays_host, uint32_t n_rays, PtHit* hits_host) {

@@ -16,6 +16,8 @@
 //   k_accumulate  running mean over frames.
 #pragma once
 
+#include <hip/hip_fp16.h>
+
 #include "pt_trace.h"
 
 #ifndef PT_PATHS_MIN_WAVES
@@ -713,6 +715,16 @@ __global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_d
     o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
     o.uv[0] = h.u; o.uv[1] = h.v;
     hits[i] = o;
+}
+
+// RGBA f32 -> RGBA binary16, round to nearest even (the reference's render target is Rgba16Float, src/shader.rs:321)
+__global__ void k_pack_f16(const float4* __restrict__ img, uint2* __restrict__ out, uint32_t n_pixels) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const float4 v = img[i];
+    const uint32_t x = __half_as_ushort(__float2half_rn(v.x)), y = __half_as_ushort(__float2half_rn(v.y));
+    const uint32_t z = __half_as_ushort(__float2half_rn(v.z)), w = __half_as_ushort(__float2half_rn(v.w));
+    out[i] = make_uint2(x | (y << 16), z | (w << 16));
 }
 
 // acc += frame; out = acc / n_frames  (radiance accumulation across frames; RGB only, A stays 1)

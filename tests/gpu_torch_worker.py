@@ -29,8 +29,13 @@ with abi.Context() as ctx:
     parts = [render_fn(scene.frame(part_index=k, part_count=2)) for k in range(2)]  # two ranks' work on one device
     both = (parts[0] + parts[1]).cpu().numpy()
     vf = ptdist.DistributedRenderer(render_fn, 0, 1, "virtual_frames").render(lambda **kw: scene.frame(**kw)).cpu().numpy()
+    half = torch.zeros((scene.height, scene.width, 4), dtype=torch.float16, device=dev)
+    ctx.render_device(scene.frame(flags=abi.PT_FRAME_OUTPUT_F16), half.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    half = half.cpu().numpy()
 ref = oracle_render(scene, scene.frame())["image"]
 assert np.array_equal(full.view(np.uint32), ref.view(np.uint32)), "tiles mode differs"
 assert np.array_equal(both.view(np.uint32), ref.view(np.uint32)), "sum of partitions differs"
 assert np.array_equal(vf.view(np.uint32), ref.view(np.uint32)), "virtual frame of rank 0 differs"
+assert np.array_equal(half.view(np.uint16), ref.astype(np.float16).view(np.uint16)), "binary16 output differs"
 print("ok")

@@ -282,6 +282,27 @@ def test_accumulation_is_mean_of_frames():
 
 
 # ---- edge cases and error behaviour -------------------------------------------------------------
+def test_output_f16_and_pinned_host_buffer():
+    """PT_FRAME_OUTPUT_F16 writes the f32 result rounded to nearest-even binary16 (the reference's Rgba16Float
+    target, src/shader.rs:321); a page-locked staging buffer from pt_host_alloc only changes how fast the copy is."""
+    scene = scenes.cornell_box(64, 48, 4, 10)
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        ref = ctx.render(scene.frame())
+        want16 = ref.astype(np.float16)
+        got16 = ctx.render(scene.frame(flags=abi.PT_FRAME_OUTPUT_F16))
+        assert got16.dtype == np.float16 and np.array_equal(got16.view(np.uint16), want16.view(np.uint16))
+        staging = ctx.host_array(ref.shape, np.float32)
+        staging16 = ctx.host_array(ref.shape, np.float16)
+        for _ in range(2):
+            out = ctx.render(scene.frame(), out=staging)
+            assert out is staging and np.array_equal(staging.view(np.uint32), ref.view(np.uint32))
+            ctx.render(scene.frame(flags=abi.PT_FRAME_OUTPUT_F16), out=staging16)
+            assert np.array_equal(staging16.view(np.uint16), want16.view(np.uint16))
+        with pytest.raises(ValueError):
+            ctx.render(scene.frame(), out=staging16)   # wrong element type for this frame
+
+
 def test_empty_scene_renders_sky():
     b = scenes.SceneBuilder()
     scene = b.build("empty", scenes.Camera((3, 3, 3), (0, 0, 0)), sky_color=(0.1, 0.2, 0.4), width=40, height=24, samples=3, bounces=5)
