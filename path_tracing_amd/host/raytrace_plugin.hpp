@@ -9,6 +9,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -52,6 +53,83 @@ struct RayTraceMeta {
     std::vector<PtTexture> textures;
     std::vector<float> texture_data;
     bool meshes_dirty = true, materials_dirty = true, objects_dirty = true;
+};
+
+// bevy_render::render_resource::TextureFormat, the variants the reference accepts (src/data.rs:104-150)
+enum class TextureFormat { Rgba8UnormSrgb, Rgba16Float, Rgb9e5Ufloat, R8Unorm, Rg8Unorm, Other };
+
+// binary16 bit pattern -> f32 (what `f16 as f32` does: exact)
+inline float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {  // subnormal half: normalise
+            int e = -1;
+            do { man <<= 1; ++e; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7F800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    static_assert(sizeof f == sizeof bits, "f32");
+    std::memcpy(&f, &bits, sizeof f);
+    return f;
+}
+
+// reference src/data.rs:53-56 and :99-160 (TextureData::append_texture): how every image asset is flattened into
+// the f32 texel pool, quirks included (Rgba16Float texels are also scaled by 1/255; the Rgb9e5Ufloat branch does its
+// own u8 bit arithmetic). A format the reference panics on throws std::invalid_argument here.
+struct TextureData {
+    std::vector<float> data;
+
+    PtTexture append_texture(const uint8_t* bytes, size_t n_bytes, uint32_t width, uint32_t height, TextureFormat format) {
+        const float DIV_255 = 1.0f / 255.0f;
+        const uint32_t offset = (uint32_t)data.size();
+        uint32_t channels = 0;
+        switch (format) {
+            case TextureFormat::Rgba8UnormSrgb:
+            case TextureFormat::R8Unorm:
+            case TextureFormat::Rg8Unorm:
+                for (size_t i = 0; i < n_bytes; ++i) data.push_back((float)bytes[i] * DIV_255);
+                channels = format == TextureFormat::Rgba8UnormSrgb ? 4u : (format == TextureFormat::R8Unorm ? 1u : 2u);
+                break;
+            case TextureFormat::Rgba16Float:
+                if (n_bytes % 2) throw std::invalid_argument("Rgba16Float image data has an odd number of bytes");
+                for (size_t i = 0; i < n_bytes; i += 2)
+                    data.push_back(half_bits_to_float((uint16_t)(bytes[i] | (bytes[i + 1] << 8))) * DIV_255);
+                channels = 4;
+                break;
+            case TextureFormat::Rgb9e5Ufloat:
+                if (n_bytes % 4) throw std::invalid_argument("Rgb9e5Ufloat image data is not a multiple of 4 bytes");
+                for (size_t i = 0; i < n_bytes; i += 4) {
+                    const uint8_t* d = bytes + i;
+                    const uint8_t e = (uint8_t)((uint8_t)(d[3] << 2) & 0b011111);
+                    const uint8_t r[2] = {(uint8_t)(e | (d[0] >> 7)), (uint8_t)((uint8_t)(d[0] << 1) | ((d[1] & 0b1) >> 7))};
+                    const uint8_t g[2] = {(uint8_t)(e | ((d[1] & 0b01) >> 6)), (uint8_t)((uint8_t)(d[1] << 2) | ((d[2] & 0b11) >> 6))};
+                    const uint8_t b[2] = {(uint8_t)(e | ((d[2] & 0b001) >> 5)), (uint8_t)((uint8_t)(d[2] << 3) | ((d[3] & 0b111) >> 5))};
+                    data.push_back(half_bits_to_float((uint16_t)(r[0] | (r[1] << 8))));
+                    data.push_back(half_bits_to_float((uint16_t)(g[0] | (g[1] << 8))));
+                    data.push_back(half_bits_to_float((uint16_t)(b[0] | (b[1] << 8))));
+                }
+                channels = 3;
+                break;
+            default:
+                throw std::invalid_argument("Texture format is not supported.");
+        }
+        PtTexture t;
+        t.width = width;
+        t.height = height;
+        t.offset = offset;
+        t.format = channels;
+        return t;
+    }
 };
 
 class RayTracePlugin;

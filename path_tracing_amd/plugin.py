@@ -66,6 +66,15 @@ class RayTraceMeta:
         self.materials, self.textures, self.texture_data = materials, textures, texture_data
         self._dirty.add("materials")
 
+    def set_images(self, materials, images):
+        """extract_textures (reference src/extract.rs:257-295): flatten every image asset, in order, with
+        TextureData::append_texture. `images` is a sequence of (data, width, height, format_name)."""
+        from .textures import TextureData
+        td = TextureData()
+        for data, width, height, fmt in images:
+            td.append_texture(data, width, height, fmt)
+        self.set_materials(materials, td.texture_array(), td.data)
+
     def set_objects(self, objects, emissives=None):
         self.objects = objects
         if emissives is not None:
