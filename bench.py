@@ -116,16 +116,35 @@ def main():
     out = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
     stream = torch.cuda.current_stream(device)
 
+    # N > 1: the all-reduce of frame i runs on a second stream while frame i+1 is traced (two image buffers), so a
+    # step costs max(render, reduce) instead of their sum; every reduction is complete before the closing
+    # synchronize of the timed region. N == 1: one buffer, one stream.
+    bufs = [out, torch.zeros_like(out)] if world > 1 else [out]
+    comm_stream = torch.cuda.Stream(device) if world > 1 else None
+    rendered = [torch.cuda.Event() for _ in bufs]
+    reduced = [torch.cuda.Event() for _ in bufs]
+    step_no = [0]
+
     def step():
-        ctx.render_device(frame, out.data_ptr(), stream.cuda_stream)
-        if world > 1:
+        k = step_no[0] % len(bufs)
+        step_no[0] += 1
+        buf = bufs[k]
+        if world == 1:
+            ctx.render_device(frame, buf.data_ptr(), stream.cuda_stream)
+            return
+        stream.wait_event(reduced[k])            # this buffer's previous reduction (two steps ago) has finished
+        ctx.render_device(frame, buf.data_ptr(), stream.cuda_stream)
+        rendered[k].record(stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(rendered[k])
             if args.backend == "nccl":
-                dist.all_reduce(out, op=dist.ReduceOp.SUM)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
             else:
-                host = out.cpu()
+                host = buf.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                out.copy_(host)
-            out.mul_(1.0 / world)
+                buf.copy_(host)
+            buf.mul_(1.0 / world)
+            reduced[k].record(comm_stream)
 
     # detailed work counters from one untimed pass (slower kernel variant)
     ctx.set_stats_detail(True)
@@ -148,6 +167,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    mean_img = float(bufs[(step_no[0] - 1) % len(bufs)][..., :3].mean().item())   # the last (reduced) image
 
     # kernel durations (HIP events recorded by the library on the launch stream), one step at a time
     kernel_ms, paths_ms, primary_ms = [], [], []
@@ -159,7 +179,6 @@ def main():
         paths_ms.append(st["paths_ms"])
         primary_ms.append(st["primary_ms"])
     st = ctx.stats()
-    mean_img = float(out[..., :3].mean().item())
 
     rays_local = int(st["rays"])
     t_max = dt

@@ -196,7 +196,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
-        if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; }
+        if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; else if (v == 8 || v == 16 || v == 32) ctx->chunk_pixels = (uint32_t)v; }
         std::snprintf(ctx->info, sizeof ctx->info, "pt_amd abi %d | %s %s | %d CUs | %d MHz | %.0f GiB", PT_ABI_VERSION, prop.name,
                       prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1073741824.0);
         hipError_t e = hipSetDevice(ctx->device);
