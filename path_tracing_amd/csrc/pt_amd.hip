@@ -52,11 +52,25 @@ struct FrameKey {
     float wfv[16], vfc[16];
 };
 
+// What the host reads back about a frame once it has finished. Two of them, so that the caller can enqueue frame
+// n+1 while frame n is still running (the launch overhead then hides behind the previous frame's kernels); the
+// device-side work buffers are shared, which stream order makes safe.
+struct FrameSlot {
+    hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr;
+    DevBuf counters, counters_k1;
+    bool pending = false;   // enqueued, not read back yet
+    bool detail = false;    // rendered with detailed statistics
+    uint64_t paths = 0, primary = 0, primary_traced = 0;
+};
+
 struct pt_ctx {
     PtConfig cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr, evb0 = nullptr, evb1 = nullptr;
+    hipEvent_t evb0 = nullptr, evb1 = nullptr;
+    FrameSlot slot[2];            // host-visible records of the two most recent frames
+    uint64_t frame_seq = 0;       // frames enqueued so far; frame n uses slot[n & 1]
+    hipStream_t last_frame_stream = nullptr;
     std::string err;
     char info[256] = {0};
 
@@ -70,7 +84,7 @@ struct pt_ctx {
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors;
     // frame outputs
-    DevBuf d_out, d_out16, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_counters, d_rays, d_hits, d_paths, d_counters_k1, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
+    DevBuf d_out, d_out16, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_rays, d_hits, d_paths, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
@@ -88,6 +102,7 @@ struct pt_ctx {
     uint32_t wave_log_records = 0;
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
     std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
+    bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
     uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
     uint32_t tlas_refits = 0;     // refits since that build
@@ -99,10 +114,7 @@ struct pt_ctx {
     uint32_t aux_w = 0, aux_h = 0;
     uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
     bool stats_detail = false;
-    bool last_detail = false;     // the frame in flight was rendered with detailed statistics
-    bool timing_pending = false;
     PtStats stats{};
-    uint64_t last_paths = 0, last_primary = 0, last_primary_traced = 0;
 };
 
 namespace {
@@ -167,6 +179,7 @@ int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t
 }
 
 int rebuild_objects(pt_ctx* ctx);
+int finish_timing(pt_ctx* ctx);
 
 }  // namespace
 
@@ -195,19 +208,22 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (const char* e = std::getenv("PT_AMD_REFILL_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_min = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
+        if (std::getenv("PT_AMD_NO_QUEUE_AHEAD")) ctx->queue_ahead = false;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; else if (v == 8 || v == 16 || v == 32) ctx->chunk_pixels = (uint32_t)v; }
         std::snprintf(ctx->info, sizeof ctx->info, "pt_amd abi %d | %s %s | %d CUs | %d MHz | %.0f GiB", PT_ABI_VERSION, prop.name,
                       prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1073741824.0);
         hipError_t e = hipSetDevice(ctx->device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
-        if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
-        if (e == hipSuccess) e = hipEventCreate(&ctx->evm);
+        for (FrameSlot& sl : ctx->slot) {
+            if (e == hipSuccess) e = hipEventCreate(&sl.ev0);
+            if (e == hipSuccess) e = hipEventCreate(&sl.ev1);
+            if (e == hipSuccess) e = hipEventCreate(&sl.evm);
+            if (e == hipSuccess) e = sl.counters.ensure(sizeof(DCounters));
+            if (e == hipSuccess) e = sl.counters_k1.ensure(sizeof(DCounters));
+        }
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb0);
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb1);
-        if (e == hipSuccess) e = ctx->d_counters.ensure(sizeof(DCounters));
-        if (e == hipSuccess) e = ctx->d_counters_k1.ensure(sizeof(DCounters));
         if (e != hipSuccess) {
             std::string m = std::string("pt_create: ") + hipGetErrorString(e);
             pt_destroy(ctx);
@@ -232,12 +248,17 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_out16, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
-                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_counters, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_counters_k1, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
+                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
     for (DevBuf* b : bufs) b->release();
     for (void* p : ctx->host_allocs) (void)hipHostFree(p);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->evm) (void)hipEventDestroy(ctx->evm);
+    for (FrameSlot& sl : ctx->slot) {
+        if (sl.ev1 && sl.pending) (void)hipEventSynchronize(sl.ev1);
+        sl.counters.release();
+        sl.counters_k1.release();
+        if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+        if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+        if (sl.evm) (void)hipEventDestroy(sl.evm);
+    }
     if (ctx->evb0) (void)hipEventDestroy(ctx->evb0);
     if (ctx->evb1) (void)hipEventDestroy(ctx->evb1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -256,6 +277,7 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
                      const PtVertex* vertices, uint32_t n_vertices) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
+        { int rc_wait = finish_timing(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
         if ((n_meshes && !meshes) || (n_indices && !indices) || (n_vertices && !vertices))
             return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_meshes: null array with non-zero count");
         PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -375,6 +397,7 @@ int pt_upload_materials(pt_ctx* ctx, const PtMaterial* materials, uint32_t n_mat
                         uint32_t n_textures, const float* texture_data, uint32_t n_texture_data) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
+        { int rc_wait = finish_timing(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
         if ((n_materials && !materials) || (n_textures && !textures) || (n_texture_data && !texture_data))
             return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_materials: null array with non-zero count");
         for (uint32_t m = 0; m < n_materials; ++m) {
@@ -410,6 +433,7 @@ int pt_upload_materials(pt_ctx* ctx, const PtMaterial* materials, uint32_t n_mat
 int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
+        { int rc_wait = finish_timing(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
         if (n_objects && !objects) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_objects: null array with non-zero count");
         if (n_objects >= 0x7FFFFFFFu) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_upload_objects: too many objects");
         for (uint32_t o = 0; o < n_objects; ++o) {
@@ -578,29 +602,30 @@ SceneView make_view(const pt_ctx* ctx) {
     return v;
 }
 
-int finish_timing(pt_ctx* ctx) {
-    if (!ctx->timing_pending) return PT_OK;
-    PT_HIP(ctx, hipEventSynchronize(ctx->ev1));
+// Wait for the frame recorded in `sl` and take its timings and counters into ctx->stats.
+int finish_slot(pt_ctx* ctx, FrameSlot& sl) {
+    if (!sl.pending) return PT_OK;
+    PT_HIP(ctx, hipEventSynchronize(sl.ev1));
     float ms = 0.0f;
-    PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    PT_HIP(ctx, hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
     DCounters c;
-    PT_HIP(ctx, hipMemcpy(&c, ctx->d_counters.p, sizeof c, hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost));
     float ms_primary = 0.0f;
-    PT_HIP(ctx, hipEventElapsedTime(&ms_primary, ctx->ev0, ctx->evm));
+    PT_HIP(ctx, hipEventElapsedTime(&ms_primary, sl.ev0, sl.evm));
     ctx->stats.trace_ms = ms;
     ctx->stats.primary_ms = ms_primary;
     ctx->stats.paths_ms = ms - ms_primary;
     ctx->stats.trace_launches = 2;
-    ctx->stats.rays = c.rays + ctx->last_primary_traced;
+    ctx->stats.rays = c.rays + sl.primary_traced;
     ctx->stats.xforms = c.xforms;
     ctx->stats.box_tests = c.box_tests;
     ctx->stats.tri_tests = c.tri_tests;
     ctx->stats.shades = c.shades;
     ctx->stats.hits = c.hits;
     ctx->stats.primary_xforms = ctx->stats.primary_box_tests = ctx->stats.primary_tri_tests = ctx->stats.primary_hits = 0;
-    if (ctx->last_detail) {
+    if (sl.detail) {
         DCounters k1;
-        PT_HIP(ctx, hipMemcpy(&k1, ctx->d_counters_k1.p, sizeof k1, hipMemcpyDeviceToHost));
+        PT_HIP(ctx, hipMemcpy(&k1, sl.counters_k1.p, sizeof k1, hipMemcpyDeviceToHost));
         ctx->stats.primary_xforms = k1.xforms;
         ctx->stats.primary_box_tests = k1.box_tests;
         ctx->stats.primary_tri_tests = k1.tri_tests;
@@ -616,11 +641,18 @@ int finish_timing(pt_ctx* ctx) {
     ctx->stats.wave_life_max = c.wave_life_max;
     ctx->stats.waves = c.waves;
     for (int k = 0; k < 32; ++k) ctx->stats.wave_life_hist[k] = c.life_hist[k];
-    ctx->stats.paths = ctx->last_paths;
-    ctx->stats.rays_reference = c.rays + ctx->last_primary_traced + ctx->last_primary;
+    ctx->stats.paths = sl.paths;
+    ctx->stats.rays_reference = c.rays + sl.primary_traced + sl.primary;
     ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u) | (ctx->tlas_refitted ? 4u : 0u);
-    ctx->timing_pending = false;
+    sl.pending = false;
     return PT_OK;
+}
+
+// All frames in flight, oldest first, so that ctx->stats ends up describing the most recent one.
+int finish_timing(pt_ctx* ctx) {
+    int rc = finish_slot(ctx, ctx->slot[ctx->frame_seq & 1]);
+    if (rc != PT_OK) return rc;
+    return finish_slot(ctx, ctx->slot[(ctx->frame_seq + 1) & 1]);
 }
 
 // Which closest-hit organisation the frame kernels use, and the LDS layout of the staged scene for PT_MODE_LDS:
@@ -665,10 +697,20 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     if ((uint64_t)f->width * f->height > (1ull << 28)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: frame larger than 2^28 pixels");
     const uint32_t pc = f->part_count ? f->part_count : 1u;
     if (f->part_index >= pc) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: part_index >= part_count");
-    rc = finish_timing(ctx);
+    // This frame's record replaces the one of the frame before the previous one, which has to be complete; the
+    // previous frame may still be running (same stream: its kernels come first). Anything that is not plain
+    // back-to-back rendering on one stream waits for everything.
+    FrameSlot& sl = ctx->slot[ctx->frame_seq & 1];
+    const FrameSlot& prev = ctx->slot[(ctx->frame_seq + 1) & 1];
+    if (s != ctx->last_frame_stream || ctx->stats_detail || prev.detail || !ctx->queue_ahead) rc = finish_timing(ctx);
+    else rc = finish_slot(ctx, sl);
     if (rc != PT_OK) return rc;
 
     const size_t n_pix = (size_t)f->width * f->height;
+    if ((ctx->aux_w != f->width || ctx->aux_h != f->height) && prev.pending) {   // buffers are about to be re-allocated
+        rc = finish_timing(ctx);
+        if (rc != PT_OK) return rc;
+    }
     PT_HIP(ctx, ctx->d_aux_obj.ensure(4 * n_pix));
     PT_HIP(ctx, ctx->d_aux_flat.ensure(4 * n_pix));
     PT_HIP(ctx, ctx->d_aux_t.ensure(4 * n_pix));
@@ -693,7 +735,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     fp.tiles_y = div_up(f->height, 8);
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     fp.n_local_tiles = (f->part_index < n_tiles) ? (n_tiles - f->part_index + pc - 1) / pc : 0u;
-    PT_HIP(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
+    PT_HIP(ctx, hipMemsetAsync(sl.counters.p, 0, sizeof(DCounters), s));
     if (pc > 1) {
         PT_HIP(ctx, hipMemsetAsync(out, 0, 16 * n_pix, s));
         PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_obj.p, 0xFF, 4 * n_pix, s));
@@ -721,16 +763,16 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     SceneView sv = make_view(ctx);
     const uint32_t depth = stack_depth_needed(ctx);
     const bool st = ctx->stats_detail;
-    ctx->last_detail = st;
+    sl.detail = st;
     float4* o4 = reinterpret_cast<float4*>(out);
     uint32_t* ao = ctx->d_aux_obj.as<uint32_t>();
     uint32_t* af = ctx->d_aux_flat.as<uint32_t>();
     float* at = ctx->d_aux_t.as<float>();
     uint32_t* ar = ctx->d_aux_rays.as<uint32_t>();
     PathRec* recs = ctx->d_paths.as<PathRec>();
-    DCounters* dc = ctx->d_counters.as<DCounters>();
+    DCounters* dc = sl.counters.as<DCounters>();
 
-    PT_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    PT_HIP(ctx, hipEventRecord(sl.ev0, s));
     // 1. primary pass: one wave per tile
     LdsScene ls;
     const int mode = scene_mode(ctx, &ls);
@@ -747,9 +789,9 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         }
     }
     if (st) {
-        PT_HIP(ctx, hipMemcpyAsync(ctx->d_counters_k1.p, ctx->d_counters.p, sizeof(DCounters), hipMemcpyDeviceToDevice, s));
+        PT_HIP(ctx, hipMemcpyAsync(sl.counters_k1.p, sl.counters.p, sizeof(DCounters), hipMemcpyDeviceToDevice, s));
     }
-    PT_HIP(ctx, hipEventRecord(ctx->evm, s));
+    PT_HIP(ctx, hipEventRecord(sl.evm, s));
     // 2. path pass: persistent waves, as many workgroups as fit on the chip at once (fewer for small frames); they
     //    pull list entries from a counter until the list is exhausted
     if (fp.bounces > 0 && fp.samples > 0 && fp.n_local_tiles) {
@@ -820,8 +862,6 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
                                   order_info, o4, ar, dc, wlog);
         PT_HIP(ctx, hipGetLastError());
     }
-    PT_HIP(ctx, hipEventRecord(ctx->ev1, s));
-    ctx->timing_pending = true;
     ctx->hint_key = key;
     ctx->hint_valid = f->settings.samples > 0u && f->settings.bounces > 0u;
     // pixels of this partition
@@ -835,9 +875,9 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
             local_pixels += (uint64_t)w * h;
         }
     }
-    ctx->last_paths = local_pixels * fp.samples;
-    ctx->last_primary = (fp.bounces > 0 && fp.samples > 0) ? local_pixels * (uint64_t)(fp.samples - 1) : 0;
-    ctx->last_primary_traced = (fp.bounces > 0 && fp.samples > 0) ? local_pixels : 0;  // one primary ray per pixel (k_primary)
+    sl.paths = local_pixels * fp.samples;
+    sl.primary = (fp.bounces > 0 && fp.samples > 0) ? local_pixels * (uint64_t)(fp.samples - 1) : 0;
+    sl.primary_traced = (fp.bounces > 0 && fp.samples > 0) ? local_pixels : 0;  // one primary ray per pixel (k_primary)
 
     if (f->flags & (PT_FRAME_ACCUMULATE | PT_FRAME_RESET)) {
         if ((f->flags & PT_FRAME_RESET) || ctx->acc_w != f->width || ctx->acc_h != f->height) {
@@ -854,6 +894,10 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
             PT_HIP(ctx, hipGetLastError());
         }
     }
+    PT_HIP(ctx, hipEventRecord(sl.ev1, s));
+    sl.pending = true;
+    ctx->frame_seq++;
+    ctx->last_frame_stream = s;
     return PT_OK;
 }
 
