@@ -126,16 +126,20 @@ PT_DEV bool slab_test(const SlabRay& s, float4 lo, float4 hi, float tmax, float&
 
 // Per-lane stack walk of a binary BVH in "while-while" form: every lane first descends through internal nodes
 // until it holds a leaf (or runs out of work), then the lanes that hold a leaf process it together. This keeps the
-// expensive leaf code (object or triangle test) running with as many lanes as possible.
+// expensive leaf code (object or triangle test) running with as many lanes as possible. The descent is cut after
+// BURST nodes: with incoherent rays a few lanes on long descents would otherwise hold back every lane that
+// already has its leaf. Measured best: 2 where a leaf is one triangle test, 16 where it is a whole object test.
+#define PT_BURST_BLAS 2
+#define PT_BURST_TLAS 16
 // `tmax` is read through the reference every time, so leaves that shorten the ray tighten the culling at once.
 #define PT_WALK_DONE 0x7FFFFFFFu
-template <bool STATS, class LeafFn>
+template <bool STATS, int BURST, class LeafFn>
 PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t root, const SlabRay& sr, const float& tmax, LdsStack stk,
                      int sp0, bool active, LaneCounters& cnt, LeafFn leaf) {
     uint32_t node = active ? root : PT_WALK_DONE;
     int sp = sp0;
     while (__any(node != PT_WALK_DONE)) {
-        while (node != PT_WALK_DONE && !(node & PT_LEAF_BIT)) {
+        for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
             const BvhNode* N = &nodes[node];
             float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
             if (STATS) cnt.box_tests += 2;
@@ -155,7 +159,7 @@ PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t root, const Sla
                 node = (sp > sp0) ? stk.get(--sp) : PT_WALK_DONE;
             }
         }
-        if (node != PT_WALK_DONE) {
+        if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
             leaf(node & ~PT_LEAF_BIT, sp);
             node = (sp > sp0) ? stk.get(--sp) : PT_WALK_DONE;
         }
@@ -199,7 +203,7 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
             }
         } else {
-            bvh_walk<STATS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+            bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
                 const DTri* T = &sc.tris[tri_first + tri];
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
             });
@@ -237,7 +241,7 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                         }
                     }
                 } else {
-                    bvh_walk<STATS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+                    bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
                         const DTri* T = &sc.tris[tri_first + tri];
                         changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
                     });
@@ -304,7 +308,7 @@ template <bool STATS>
 PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
     if (sc.tlas_root == PT_NONE) return;
     const SlabRay sr = world_slab_ray(ro, rd);
-    bvh_walk<STATS>(sc.tlas_nodes, sc.tlas_root, sr, best.t, stk, 0, active, cnt,
+    bvh_walk<STATS, PT_BURST_TLAS>(sc.tlas_nodes, sc.tlas_root, sr, best.t, stk, 0, active, cnt,
                     [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, ro, rd, best, stk, sp, cnt); });
 }
 
