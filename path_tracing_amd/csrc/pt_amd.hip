@@ -777,14 +777,18 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     LdsScene ls;
     const int mode = scene_mode(ctx, &ls);
     {
-        const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
-        const uint32_t grid = div_up(fp.n_local_tiles, 4);
+        const size_t scene_lds = (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
+        const bool wide = (size_t)16 * depth * 256 + scene_lds <= 64 * 1024 && !std::getenv("PT_AMD_K1_NARROW");   // 16 waves per workgroup when their stacks fit
+        const uint32_t waves = wide ? 16u : 4u;
+        const size_t lds = (size_t)waves * depth * 64 * sizeof(uint32_t) + scene_lds;
+        const uint32_t grid = (wide && pc == 1u) ? div_up(fp.tiles_x, 4) * div_up(fp.tiles_y, 4) : div_up(fp.n_local_tiles, waves);
         using PrimaryFn = void (*)(PT_SCENE_PARAMS, LdsScene, FrameParams, uint32_t, float4*, uint32_t*, uint32_t*, float*, uint32_t*, PathRec*, uint32_t*, uint32_t, DCounters*);
-        static const PrimaryFn table[3][2] = {{k_primary<PT_MODE_LIST, false>, k_primary<PT_MODE_LIST, true>},
-                                              {k_primary<PT_MODE_TLAS, false>, k_primary<PT_MODE_TLAS, true>},
-                                              {k_primary<PT_MODE_LDS, false>, k_primary<PT_MODE_LDS, true>}};
+        static const PrimaryFn table[3][2][2] = {
+            {{k_primary<PT_MODE_LIST, false, 4>, k_primary<PT_MODE_LIST, false, 16>}, {k_primary<PT_MODE_LIST, true, 4>, k_primary<PT_MODE_LIST, true, 16>}},
+            {{k_primary<PT_MODE_TLAS, false, 4>, k_primary<PT_MODE_TLAS, false, 16>}, {k_primary<PT_MODE_TLAS, true, 4>, k_primary<PT_MODE_TLAS, true, 16>}},
+            {{k_primary<PT_MODE_LDS, false, 4>, k_primary<PT_MODE_LDS, false, 16>}, {k_primary<PT_MODE_LDS, true, 4>, k_primary<PT_MODE_LDS, true, 16>}}};
         if (grid) {
-            table[mode][st ? 1 : 0]<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, fp, depth, o4, ao, af, at, ar, recs, ctx->d_cost.as<uint32_t>(), use_hint ? 1u : 0u, dc);
+            table[mode][st ? 1 : 0][wide ? 1 : 0]<<<grid, waves * 64, lds, s>>>(PT_SCENE_ARGS(sv), ls, fp, depth, o4, ao, af, at, ar, recs, ctx->d_cost.as<uint32_t>(), use_hint ? 1u : 0u, dc);
             PT_HIP(ctx, hipGetLastError());
         }
     }

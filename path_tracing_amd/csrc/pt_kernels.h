@@ -122,24 +122,39 @@ PT_DEV bool primary_is_terminal(const SceneView& sc, const HitInfo& h, v3 sky, v
     return true;
 }
 
-// ---- primary pass: one wave per 8x8 pixel tile, four tiles per workgroup --------------------------------------
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, FrameParams fp, uint32_t stack_depth, float4* __restrict__ out,
+// ---- primary pass: one wave per 8x8 pixel tile, WAVES tiles per workgroup ---------------------------------------
+// (16 where the traversal stacks leave room: the append costs one atomic per workgroup on a single address)
+template <int MODE, bool STATS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScene ls, FrameParams fp, uint32_t stack_depth, float4* __restrict__ out,
                                                  uint32_t* __restrict__ aux_obj, uint32_t* __restrict__ aux_flat,
                                                  float* __restrict__ aux_t, uint32_t* __restrict__ aux_rays,
                                                  PathRec* __restrict__ recs, uint32_t* __restrict__ cost, uint32_t use_hint,
                                                  DCounters* __restrict__ counters) {
     PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ uint32_t s_mem[];  // [4 waves][stack_depth][64 lanes], then the staged scene (PT_MODE_LDS)
-    if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + 4 * stack_depth * 64);
+    extern __shared__ uint32_t s_mem[];  // [WAVES][stack_depth][64 lanes], then the staged scene (PT_MODE_LDS)
+    if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + WAVES * stack_depth * 64);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t local_tile = blockIdx.x * 4 + wave;
-    const bool tile_ok = local_tile < fp.n_local_tiles;  // wave-uniform; the wave stays for the block-wide append below
+    // Which tile this wave takes. Whole frames with 16 waves: the workgroup covers a 4x4 group of tiles (32x32
+    // pixels), so that its entries of the path list, and with them the chunks k_paths works through, come from one
+    // compact patch of the image with similar path lengths. Otherwise: tiles in row-major order.
+    uint32_t tx, ty;
+    bool tile_ok;  // wave-uniform; a wave without a tile stays for the block-wide append below
+    if (WAVES == 16 && fp.part_count == 1u) {
+        const uint32_t groups_x = (fp.tiles_x + 3u) / 4u;
+        const uint32_t gy = blockIdx.x / groups_x, gx = blockIdx.x - gy * groups_x;
+        tx = gx * 4u + (wave & 3u);
+        ty = gy * 4u + (wave >> 2);
+        tile_ok = tx < fp.tiles_x && ty < fp.tiles_y;
+    } else {
+        const uint32_t local_tile = blockIdx.x * WAVES + wave;
+        tile_ok = local_tile < fp.n_local_tiles;
+        const uint32_t tile = local_tile * fp.part_count + fp.part_index;
+        ty = tile / fp.tiles_x;
+        tx = tile - ty * fp.tiles_x;
+    }
     LdsStack stk;
     stk.base = &s_mem[wave * stack_depth * 64 + lane];
 
-    const uint32_t tile = local_tile * fp.part_count + fp.part_index;
-    const uint32_t ty = tile / fp.tiles_x, tx = tile - ty * fp.tiles_x;
     const uint32_t px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
     const bool valid = tile_ok && px < fp.width && py < fp.height;
     const uint32_t pix = py * fp.width + px;
@@ -202,12 +217,13 @@ __global__ __launch_bounds__(256) void k_primary(PT_SCENE_PARAMS, LdsScene ls, F
     }
     // append the workgroup's surviving pixels to the path list: one atomic per workgroup (a single counter takes
     // only ~90 atomics per microsecond, so one per wave would cost more than the tracing)
-    __shared__ uint32_t s_count[4], s_base;
+    __shared__ uint32_t s_count[WAVES], s_base;
     const unsigned long long m = __ballot(to_list);
     if (lane == 0) s_count[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t n = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+        uint32_t n = 0;
+        for (int w = 0; w < WAVES; ++w) n += s_count[w];
         s_base = n ? atomicAdd(&counters->n_paths, n) : 0u;
     }
     __syncthreads();
