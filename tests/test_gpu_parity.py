@@ -194,6 +194,34 @@ def test_boxes_1080p_accel_invariance_and_accounting():
     assert np.array_equal(a["primary_flat_id"][y0:y1, x0:x1], ref["primary_flat_id"])
 
 
+def test_boxes_1080p_repeated_frames_bit_identical(monkeypatch):
+    """Benchmark size: the first frame of a context runs in list order, later frames in the order the previous
+    frame's ray counts suggest, with the samples cut into sweeps. All of them, and a context with sweeps and hints
+    switched off, must produce the same bits, aux planes included."""
+    scene = scenes.boxes(1920, 1080, 64, 10)
+    frame = scene.frame()
+    with monkeypatch.context() as mp:
+        mp.setenv("PT_AMD_SWEEPS", "1")
+        mp.setenv("PT_AMD_NO_COST_HINTS", "1")
+        with abi.Context() as ctx:
+            ctx.upload_scene(scene)
+            ref = ctx.render(frame)
+            ref_rays = ctx.read_aux(abi.PT_AUX_RAY_COUNT)
+            ref_stats = ctx.stats()
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        for _ in range(3):
+            img = ctx.render(frame)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+            assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), ref_rays)
+            assert ctx.stats()["rays"] == ref_stats["rays"] and ctx.stats()["rays_reference"] == int(ref_rays.astype(np.uint64).sum())
+        # another `time` changes the seeds but is the same view: hints stay in use, the image is that of a fresh context
+        img_t = ctx.render(scene.frame(time=1.5))
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        assert np.array_equal(ctx.render(scene.frame(time=1.5)).view(np.uint32), img_t.view(np.uint32))
+
+
 def test_million_triangles_tlas_vs_loop_and_oracle_crop():
     scene = scenes.instanced_boxes(83334, 1920, 1080, 1, 10)
     assert scene.n_triangles == 1000008
