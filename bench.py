@@ -9,6 +9,9 @@ rank renders the same frame as an independent virtual frame (its own `time`, hen
 seeds, exactly how the reference de-correlates successive frames) and the radiance buffers are summed
 with one RCCL all-reduce per step: N x 64 spp per step, per-GPU work fixed (weak scaling).
 
+Frames are kept in flight (--frames-in-flight, default 2): that many contexts take the frames in turn on their own
+streams, so the start of a frame overlaps the tail of the previous one; results are those of one context.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -21,6 +24,12 @@ import time
 from pathlib import Path
 
 import numpy as np
+
+# Frames in flight run on separate HIP streams; they only overlap on the GPU if each stream gets a hardware queue of
+# its own. HIP's default of 4 queues per process is shared with the contexts' upload streams, torch's streams and
+# RCCL's, so ask for 8 (read by the runtime when it initialises, i.e. before torch is imported).
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -80,6 +89,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (invalidates the headline config)")
     ap.add_argument("--cpu-spp", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="contexts that take the frames in turn (1: strictly one frame at a time)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path with every rank on GPU 0")
     args = ap.parse_args()
 
@@ -111,30 +121,34 @@ def main():
     frame = scene.frame(time=virtual_frame_time(rank))
     W, H = frame.width, frame.height
 
-    ctx = abi.Context(device=local_rank)
-    ctx.upload_scene(scene)
-    out = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
-    stream = torch.cuda.current_stream(device)
-
-    # N > 1: the all-reduce of frame i runs on a second stream while frame i+1 is traced (two image buffers), so a
-    # step costs max(render, reduce) instead of their sum; every reduction is complete before the closing
-    # synchronize of the timed region. N == 1: one buffer, one stream.
-    bufs = [out, torch.zeros_like(out)] if world > 1 else [out]
+    # Frames in flight: F contexts (the scene arrays are small), each with its own stream and image buffer, take
+    # the frames in turn, so the tail of one frame's path kernel (waves running out of work) is filled by the
+    # start of the next frame. For N > 1 the all-reduce of a frame runs on one more stream while later frames are
+    # traced. Every frame and every reduction is complete before the closing synchronize of the timed region.
+    F = max(1, args.frames_in_flight)
+    ctxs = [abi.Context(device=local_rank) for _ in range(F)]
+    for c in ctxs:
+        c.upload_scene(scene)
+    ctx = ctxs[0]
+    bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(F)]
+    out = bufs[0]
+    streams = [torch.cuda.Stream(device) for _ in range(F)]
+    stream = streams[0]
     comm_stream = torch.cuda.Stream(device) if world > 1 else None
     rendered = [torch.cuda.Event() for _ in bufs]
     reduced = [torch.cuda.Event() for _ in bufs]
     step_no = [0]
 
     def step():
-        k = step_no[0] % len(bufs)
+        k = step_no[0] % F
         step_no[0] += 1
         buf = bufs[k]
         if world == 1:
-            ctx.render_device(frame, buf.data_ptr(), stream.cuda_stream)
+            ctxs[k].render_device(frame, buf.data_ptr(), streams[k].cuda_stream)
             return
-        stream.wait_event(reduced[k])            # this buffer's previous reduction (two steps ago) has finished
-        ctx.render_device(frame, buf.data_ptr(), stream.cuda_stream)
-        rendered[k].record(stream)
+        streams[k].wait_event(reduced[k])        # this buffer's previous reduction (F steps ago) has finished
+        ctxs[k].render_device(frame, buf.data_ptr(), streams[k].cuda_stream)
+        rendered[k].record(streams[k])
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(rendered[k])
             if args.backend == "nccl":
@@ -167,7 +181,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    mean_img = float(bufs[(step_no[0] - 1) % len(bufs)][..., :3].mean().item())   # the last (reduced) image
+    mean_img = float(bufs[(step_no[0] - 1) % F][..., :3].mean().item())   # the last (reduced) image
 
     # kernel durations (HIP events recorded by the library on the launch stream), one step at a time
     kernel_ms, paths_ms, primary_ms = [], [], []
@@ -232,7 +246,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "scene": scene.name, "width": W, "height": H, "spp_per_gpu": scene.samples,
                        "bounces": scene.bounces, "objects": int(scene.objects.size), "triangles": scene.n_triangles,
-                       "multi_gpu": "one virtual frame per GPU + RCCL all-reduce(sum) of the f32 radiance buffer" if world > 1 else "single GPU"},
+                       "multi_gpu": "one virtual frame per GPU + RCCL all-reduce(sum) of the f32 radiance buffer" if world > 1 else "single GPU",
+                       "frames_in_flight": F},
             "rays_per_step": rays_total,
             "rays_definition": "closest-hit queries executed; the primary ray of a pixel is identical for all of its samples "
                                "(src/raytrace.wgsl:223) and is traced once, the reference would trace rays_reference_per_step",
@@ -255,7 +270,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_spp, scene.samples))
         print(json.dumps(line), flush=True)
 
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
