@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload boxes] [--no-cpu-baseline]
 
-N = 1 renders BASELINE.json configs[1]: the examples/boxes.rs scene at 1920x1080, 64 spp, 10 bounces,
+N = 1 renders the headline configuration: the examples/boxes.rs scene at 1920x1080, 64 spp, 10 bounces,
 scene and image resident in HBM. For N > 1 (launched by torch.distributed.run, one rank per GPU) every
 rank renders the same frame as an independent virtual frame (its own `time`, hence its own per-pixel
 seeds, exactly how the reference de-correlates successive frames) and the radiance buffers are summed
