@@ -103,6 +103,9 @@ struct pt_ctx {
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
     std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
     bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
+    uint64_t last_n_paths = ~0ull; // entries of the path list of the last frame read back
+    bool lds_blas = true;         // object-list scenes: stage the biggest BLAS that fits in LDS (k_paths)
+    uint32_t lds_per_cu = 160 * 1024;
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
     uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
     uint32_t tlas_refits = 0;     // refits since that build
@@ -208,6 +211,8 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (const char* e = std::getenv("PT_AMD_REFILL_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_min = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
+        if (std::getenv("PT_AMD_NO_LDS_BLAS")) ctx->lds_blas = false;
+        if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
         if (std::getenv("PT_AMD_NO_QUEUE_AHEAD")) ctx->queue_ahead = false;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; else if (v == 8 || v == 16 || v == 32) ctx->chunk_pixels = (uint32_t)v; }
@@ -637,6 +642,7 @@ int finish_slot(pt_ctx* ctx, FrameSlot& sl) {
     ctx->stats.wave_rounds = c.rounds;
     ctx->stats.lane_rounds = c.lane_rounds;
     ctx->stats.object_passes = c.passes;
+    ctx->last_n_paths = c.n_paths;
     ctx->stats.wave_life_sum = c.wave_life_sum;
     ctx->stats.wave_life_max = c.wave_life_max;
     ctx->stats.waves = c.waves;
@@ -808,14 +814,43 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
         pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
         const size_t lds = ((size_t)4 * (depth + PT_LANE_SLOTS) * 64 + 4 * PT_SCHED_WORDS) * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
-        using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, PathParams, uint32_t, const PathRec*, PathCarry*, uint32_t*, const uint32_t*, const ChunkOrderInfo*, float4*,
+        using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, LdsBlas, PathParams, uint32_t, const PathRec*, PathCarry*, uint32_t*, const uint32_t*, const ChunkOrderInfo*, float4*,
                                  uint32_t*, DCounters*, uint4*);
-        static const PathsFn ptable[3][2] = {{k_paths<PT_MODE_LIST, false>, k_paths<PT_MODE_LIST, true>},
+        static const PathsFn ptable[4][2] = {{k_paths<PT_MODE_LIST, false>, k_paths<PT_MODE_LIST, true>},
                                              {k_paths<PT_MODE_TLAS, false>, k_paths<PT_MODE_TLAS, true>},
-                                             {k_paths<PT_MODE_LDS, false>, k_paths<PT_MODE_LDS, true>}};
-        PathsFn fn = ptable[mode][st ? 1 : 0];
+                                             {k_paths<PT_MODE_LDS, false>, k_paths<PT_MODE_LDS, true>},
+                                             {k_paths<PT_MODE_LIST_LB, false>, k_paths<PT_MODE_LIST_LB, true>}};
+        // Object-list scenes with a big mesh: its whole BLAS (and its triangles if they fit as well) goes into LDS,
+        // at the price of fewer workgroups per compute unit. Rays in such a mesh are chains of dependent node
+        // visits, each a round trip to the L2 otherwise.
+        LdsBlas lb;
+        std::memset(&lb, 0, sizeof lb);
+        int paths_mode = mode;
+        // Only when the last finished frame of this view listed so few pixels that one workgroup per compute unit
+        // takes them all anyway (a frame full of such pixels is better served by more workgroups).
+        if (mode == PT_MODE_LIST && ctx->lds_blas && use_hint && ctx->last_n_paths <= (uint64_t)ctx->n_cus * 256u * 4u) {
+            const size_t budget = (size_t)ctx->lds_per_cu - 1024 - lds;
+            uint32_t best = PT_NONE;
+            for (uint32_t m = 0; m < ctx->n_meshes; ++m) {
+                if (ctx->h_blas_nodes_base[m] == PT_NONE || ctx->h_meshes[m].tri_count < 2) continue;
+                const size_t nodes = sizeof(BvhNode) * (size_t)(ctx->h_meshes[m].tri_count - 1);
+                if (nodes <= budget && (best == PT_NONE || ctx->h_meshes[m].tri_count > ctx->h_meshes[best].tri_count)) best = m;
+            }
+            if (best != PT_NONE) {
+                lb.mesh = best;
+                lb.node_base = ctx->h_blas_nodes_base[best];
+                lb.n_nodes = ctx->h_meshes[best].tri_count - 1;
+                lb.tri_first = ctx->h_meshes[best].tri_first;
+                const size_t nodes = sizeof(BvhNode) * (size_t)lb.n_nodes, tris = sizeof(DTri) * (size_t)ctx->h_meshes[best].tri_count;
+                lb.n_tris = (nodes + tris <= budget) ? ctx->h_meshes[best].tri_count : 0u;
+                paths_mode = PT_MODE_LIST_LB;
+            }
+        }
+        const size_t lds_paths = lds + (paths_mode == PT_MODE_LIST_LB ? sizeof(BvhNode) * (size_t)lb.n_nodes + sizeof(DTri) * (size_t)lb.n_tris : 0u);
+        PathsFn fn = ptable[paths_mode][st ? 1 : 0];
+        if (lds_paths > 64 * 1024) PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_paths));
         int per_cu = 0;
-        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds));
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds_paths));
         if (per_cu < 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: the path kernel does not fit on a compute unit with this traversal stack");
         if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
         const uint32_t grid = std::min(div_up(fp.n_local_tiles, 4), (uint32_t)per_cu * ctx->n_cus);
@@ -848,7 +883,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
             wlog = ctx->d_wave_log.as<uint4>();
             ctx->wave_log_records = grid * 4u;
         }
-        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u sweeps=%u\n", mode, per_cu, grid, lds, depth, pp.chunk, pp.refill_min, pp.n_sweeps);
+        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u sweeps=%u last_n_paths=%llu\n", paths_mode, per_cu, grid, lds_paths, depth, pp.chunk, pp.refill_min, pp.n_sweeps, (unsigned long long)ctx->last_n_paths);
         const uint32_t* chunk_order = nullptr;
         const ChunkOrderInfo* order_info = nullptr;
         if (use_hint && pp.chunk == PT_CHUNK) {
@@ -862,7 +897,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
             chunk_order = order;
             order_info = info;
         }
-        fn<<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, pp, depth, recs, ctx->d_carry.as<PathCarry>(), ctx->d_sweeps_done.as<uint32_t>(), chunk_order,
+        fn<<<grid, 256, lds_paths, s>>>(PT_SCENE_ARGS(sv), ls, lb, pp, depth, recs, ctx->d_carry.as<PathCarry>(), ctx->d_sweeps_done.as<uint32_t>(), chunk_order,
                                   order_info, o4, ar, dc, wlog);
         PT_HIP(ctx, hipGetLastError());
     }

@@ -102,6 +102,21 @@ PT_DEV void stage_scene_in_lds(SceneView& sc, const LdsScene& ls, uint32_t* lds)
     sc.textures = reinterpret_cast<const DTexture*>(lds + ls.off_textures / 4);
 }
 
+// One mesh's BLAS (and, when they fit too, its triangle records) to be copied into LDS by every k_paths workgroup.
+struct LdsBlas {
+    uint32_t mesh, node_base, n_nodes, tri_first, n_tris;   // n_tris == 0: triangles stay in global memory
+};
+PT_DEV void stage_blas_in_lds(SceneView& sc, const LdsBlas& lb, uint32_t* lds) {
+    lds_copy16(lds, sc.blas_nodes + lb.node_base, lb.n_nodes * (uint32_t)sizeof(BvhNode));
+    uint32_t* tris = lds + lb.n_nodes * (uint32_t)(sizeof(BvhNode) / 4);
+    if (lb.n_tris) lds_copy16(tris, sc.tris + lb.tri_first, lb.n_tris * (uint32_t)sizeof(DTri));
+    __syncthreads();
+    sc.lb_nodes = reinterpret_cast<const BvhNode*>(lds);
+    sc.lb_tris = lb.n_tris ? reinterpret_cast<const DTri*>(tris) : nullptr;
+    sc.lb_mesh = lb.mesh;
+    sc.lb_node_base = lb.node_base;
+}
+
 PT_DEV uint32_t wave_sum_u32(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
 #define PT_SCHED_WORDS 8
 
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, PathParams pp, uint32_t stack_depth,
+__global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, LdsBlas lb, PathParams pp, uint32_t stack_depth,
                                                                     const PathRec* __restrict__ recs, PathCarry* __restrict__ carry,
                                                                     uint32_t* __restrict__ sweeps_done, const uint32_t* __restrict__ chunk_order,
                                                                     const ChunkOrderInfo* __restrict__ order_info,
@@ -351,6 +366,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     extern __shared__ uint32_t s_mem[];
     const uint32_t lds_fixed = 4 * (stack_depth + PT_LANE_SLOTS) * 64 + 4 * PT_SCHED_WORDS;
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + lds_fixed);
+    if (MODE == PT_MODE_LIST_LB) stage_blas_in_lds(sc, lb, s_mem + lds_fixed);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;
     stk.base = &s_mem[wave * stack_depth * 64 + lane];

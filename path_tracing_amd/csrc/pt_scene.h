@@ -97,6 +97,10 @@ struct SceneView {
     uint32_t _pad0;
     uint32_t tie_lowest;  // 0: equal distances go to the later (object, triangle) as in the reference; 1: to the earlier
     uint32_t _pad1;
+    // one mesh's BLAS staged in LDS by the kernel (PT_MODE_LIST_LB), null otherwise
+    const BvhNode* lb_nodes;  // its nodes; a node reference r of that mesh is lb_nodes[r - lb_node_base]
+    const DTri* lb_tris;      // its triangle records (null: they stay in global memory)
+    uint32_t lb_mesh, lb_node_base;
 };
 
 // The kernels take the scene arrays as separate `const T* __restrict__` parameters (PT_SCENE_PARAMS) and rebuild a
@@ -121,7 +125,8 @@ struct SceneScalars {
     sc.tlas_nodes = p_tlas; sc.obj_lo = p_obj_lo; sc.obj_hi = p_obj_hi; sc.materials = p_materials;                     \
     sc.textures = p_textures; sc.texture_data = p_texdata; sc.n_objects = ss.n_objects;                                 \
     sc.n_texture_data = ss.n_texture_data; sc.tlas_root = ss.tlas_root; sc.cull_boxes = ss.cull_boxes;                  \
-    sc._pad0 = 0; sc.tie_lowest = ss.tie_lowest; sc._pad1 = 0;
+    sc._pad0 = 0; sc.tie_lowest = ss.tie_lowest; sc._pad1 = 0;                                                       \
+    sc.lb_nodes = nullptr; sc.lb_tris = nullptr; sc.lb_mesh = 0xFFFFFFFFu; sc.lb_node_base = 0;
 
 // Per-frame constants.
 struct FrameParams {

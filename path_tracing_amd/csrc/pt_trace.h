@@ -134,13 +134,13 @@ PT_DEV bool slab_test(const SlabRay& s, float4 lo, float4 hi, float tmax, float&
 // `tmax` is read through the reference every time, so leaves that shorten the ray tighten the culling at once.
 #define PT_WALK_DONE 0x7FFFFFFFu
 template <bool STATS, int BURST, class LeafFn>
-PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t root, const SlabRay& sr, const float& tmax, LdsStack stk,
+PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t bias, uint32_t root, const SlabRay& sr, const float& tmax, LdsStack stk,
                      int sp0, bool active, LaneCounters& cnt, LeafFn leaf) {
     uint32_t node = active ? root : PT_WALK_DONE;
     int sp = sp0;
     while (__any(node != PT_WALK_DONE)) {
         for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
-            const BvhNode* N = &nodes[node];
+            const BvhNode* N = &nodes[node - bias];   // bias: first node of a tree that was copied somewhere on its own
             float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
             if (STATS) cnt.box_tests += 2;
             float tl, tr;
@@ -173,7 +173,7 @@ PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t root, const Sla
 // three divisions is then needed once per accepted object instead of once per visited object).
 // Meshes without a BLAS and more than this many triangles are first tested against their padded local box.
 #define PT_LOCAL_BOX_MIN_TRIS 4u
-template <bool STATS, bool PERLANE>
+template <bool STATS, bool PERLANE, bool LB = false>
 PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& best, LdsStack stk, int sp0,
                         LaneCounters& cnt) {
     const DObject* ob = &sc.objects[obj];
@@ -203,7 +203,7 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
             }
         } else {
-            bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+            bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, 0u, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
                 const DTri* T = &sc.tris[tri_first + tri];
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
             });
@@ -240,8 +240,21 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                             if (inside) changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
                         }
                     }
+                } else if (LB && m == sc.lb_mesh) {
+                    // this mesh's BLAS sits in LDS: a node visit costs an LDS read instead of a trip to the L2
+                    if (sc.lb_tris) {
+                        bvh_walk<STATS, PT_BURST_BLAS>(sc.lb_nodes, sc.lb_node_base, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+                            const DTri* T = &sc.lb_tris[tri];
+                            changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
+                        });
+                    } else {
+                        bvh_walk<STATS, PT_BURST_BLAS>(sc.lb_nodes, sc.lb_node_base, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+                            const DTri* T = &sc.tris[tri_first + tri];
+                            changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
+                        });
+                    }
                 } else {
-                    bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+                    bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, 0u, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
                         const DTri* T = &sc.tris[tri_first + tri];
                         changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
                     });
@@ -264,7 +277,7 @@ PT_DEV SlabRay world_slab_ray(v3 ro, v3 rd) {
 // each lane collects its own candidates in a bit mask and then works through them.
 // An object whose world box the ray misses cannot contain an accepted triangle, so skipping it changes nothing.
 // With sc.cull_boxes == 0 (PT_ACCEL_BRUTE) every object is a candidate: the reference's exhaustive loop.
-template <bool STATS, bool PERLANE>
+template <bool STATS, bool PERLANE, bool LB = false>
 PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
     const SlabRay sr = world_slab_ray(ro, rd);
     const uint32_t n = sc.n_objects;
@@ -297,7 +310,7 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
                 const uint32_t o = base + k;
                 mask &= ~(1u << k);
                 float tn;
-                if (!cull || slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn)) object_test<STATS, PERLANE>(sc, o, ro, rd, best, stk, 0, cnt);
+                if (!cull || slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn)) object_test<STATS, PERLANE, LB>(sc, o, ro, rd, best, stk, 0, cnt);
             }
         }
     }
@@ -308,7 +321,7 @@ template <bool STATS>
 PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
     if (sc.tlas_root == PT_NONE) return;
     const SlabRay sr = world_slab_ray(ro, rd);
-    bvh_walk<STATS, PT_BURST_TLAS>(sc.tlas_nodes, sc.tlas_root, sr, best.t, stk, 0, active, cnt,
+    bvh_walk<STATS, PT_BURST_TLAS>(sc.tlas_nodes, 0u, sc.tlas_root, sr, best.t, stk, 0, active, cnt,
                     [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, ro, rd, best, stk, sp, cnt); });
 }
 
@@ -316,6 +329,7 @@ PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
 #define PT_MODE_LIST 0  // object list culled with world boxes, scene records in global memory
 #define PT_MODE_TLAS 1  // TLAS walk
 #define PT_MODE_LDS 2   // object list, every scene record staged in LDS (small scenes)
+#define PT_MODE_LIST_LB 3  // object list, the BLAS of one mesh staged in LDS (k_paths only)
 template <int MODE, bool STATS>
 PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
     best.t = PT_T_MAX;
@@ -324,7 +338,7 @@ PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& be
     best.u = 0.0f;
     best.v = 0.0f;
     if (MODE == PT_MODE_TLAS) closest_hit_tlas<STATS>(sc, ro, rd, active, best, stk, cnt);
-    else closest_hit_list<STATS, MODE == PT_MODE_LDS>(sc, ro, rd, active, best, stk, cnt);
+    else closest_hit_list<STATS, MODE == PT_MODE_LDS, MODE == PT_MODE_LIST_LB>(sc, ro, rd, active, best, stk, cnt);
 }
 
 // The hit_record of the winner (reference src/query.wgsl:113-120), evaluated once per ray.

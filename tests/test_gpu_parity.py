@@ -244,7 +244,7 @@ def test_million_triangles_tlas_vs_loop_and_oracle_crop():
     assert (full["primary_object"] != abi.PT_U32_MAX).mean() > 0.3
 
 
-@pytest.mark.parametrize("name,spp", [("cornell", 32), ("boxes", 32), ("instanced_boxes", 8)])
+@pytest.mark.parametrize("name,spp", [("cornell", 32), ("boxes", 32), ("instanced_boxes", 8), ("scene_glb_textured", 8)])
 def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
     """The order in which k_paths takes the pixels (sample sweeps, cost hints from the previous frame, whole-chunk
     or per-lane refill) never shows in a result: repeated frames of one context and contexts with other schedules
@@ -265,9 +265,9 @@ def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
                            ray_count=ctx.read_aux(abi.PT_AUX_RAY_COUNT), accel=ctx.check_accel())
                 assert_same(got, *want)
 
-    run(3)
+    run(3)   # (the glb scene: from the second frame on its big mesh's BLAS is staged in LDS)
     for env in ({"PT_AMD_SWEEPS": "1"}, {"PT_AMD_SWEEPS": "8"}, {"PT_AMD_NO_COST_HINTS": "1"}, {"PT_AMD_REFILL_MIN": "1"},
-                {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}):
+                {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}, {"PT_AMD_NO_LDS_BLAS": "1"}):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
