@@ -202,7 +202,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
         return;
     }
 
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {};
     Best b;
     closest_hit<MODE, STATS>(sc, origin, dir0, valid, b, stk, cnt);
     bool to_list = false;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     const uint32_t total = counters->n_paths;  // written by k_primary, which ran before on the same stream
     const uint32_t n_heavy = (order_info && pp.n_sweeps > 1u) ? order_info->n_heavy : 0u;
 
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {};
     uint32_t lane_rays = 0;
     unsigned long long t_begin = 0, t_begin_real = 0;
     if (STATS) {
@@ -589,11 +589,14 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
         };
         bool pending = st == PT_ST_SHADE;
         while (__any(pending)) {
+            PT_COUNT(cnt, 0);
             // 1. (cheap) a path that ends on this hit, a miss or a black surface, restarts from the primary hit ...
             bool restarted = false;
             if (pending) {
                 bool stop;
+                PT_COUNT(cnt, 1);
                 if (h.obj != PT_NONE) {
+                    PT_COUNT(cnt, 2);
                     stop = add_emitted();
                 } else {
                     color = V3(pt_fma(ray_color.x, pp.sky[0], color.x), pt_fma(ray_color.y, pp.sky[1], color.y),
@@ -601,14 +604,16 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                     stop = true;
                 }
                 if (stop) {
+                    PT_COUNT(cnt, 3);
                     pending = next_sample();
                     restarted = pending;
                 }
             }
             // 2. ... whose surface never ends a path (k_primary finished those pixels)
-            if (restarted) (void)add_emitted();
+            if (restarted) { PT_COUNT(cnt, 4); (void)add_emitted(); }
             // 3. (expensive) so every lane that still has work scatters in the same pass
             if (pending) {
+                PT_COUNT(cnt, 5);
                 const DMaterial m = sc.materials[sc.objects[h.obj].mat];
                 v3 N = h.n;
                 if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
@@ -622,6 +627,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 bounce++;
                 if (p < PT_EPSILON || bounce >= bounces) {
                     // dark path or bounce limit: next sample; its primary hit is shaded in another pass of this loop
+                    PT_COUNT(cnt, 6);
                     pending = next_sample();
                 } else {
                     st = PT_ST_TRACE;
@@ -645,7 +651,9 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             // waves whose rays are expensive (many candidate objects) are the critical path of the launch: let them issue first
             if (cnt.passes >= PT_WAVE_PRIO_PASSES) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
+            PT_COUNT(cnt, 7);
             if (tracing) {
+                PT_COUNT(cnt, 12);
                 nrays++;
                 lane_rays++;
                 if (STATS && b.obj != PT_NONE) cnt.hits++;
@@ -663,6 +671,14 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
 
     const uint32_t r = wave_sum_u32(lane_rays);
     if (lane == 0 && r) atomicAdd(&counters->rays, (unsigned long long)r);
+#ifdef PT_EXEC_COUNTS
+    if (STATS) {
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t v = wave_sum_u32(cnt.exec[k]);
+            if (lane == 0) atomicAdd(&counters->life_hist[16 + k], v);   // debug build: the upper half of the histogram
+        }
+    }
+#endif
     if (STATS) {
         const uint32_t a = wave_sum_u32(cnt.xforms), b = wave_sum_u32(cnt.box_tests), c = wave_sum_u32(cnt.tri_tests),
                        d = wave_sum_u32(cnt.shades), e = wave_sum_u32(cnt.hits);
@@ -670,7 +686,9 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             const unsigned long long life = __builtin_amdgcn_s_memtime() - t_begin;
             atomicAdd(&counters->wave_life_sum, life);
             atomicMax(&counters->wave_life_max, life);
+#ifndef PT_EXEC_COUNTS
             { unsigned long long bkt = life >> 19; if (bkt > 31) bkt = 31; atomicAdd(&counters->life_hist[bkt], 1u); }
+#endif
             if (n_rounds) atomicAdd(&counters->waves, 1ull);
             if (wave_log) {
                 // per-wave record: start and end on the 100 MHz clock, lifetime in 16-cycle units, rounds; lane rounds,
@@ -728,7 +746,7 @@ __global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_d
         ro = V3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
         rd = V3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
     }
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {};
     Best b;
     closest_hit<MODE, false>(sc, ro, rd, valid, b, stk, cnt);
     if (!valid) return;

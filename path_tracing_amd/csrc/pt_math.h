@@ -111,7 +111,13 @@ PT_DEV void pcg3d(Rng& st) {
     st.x = x; st.y = y; st.z = z;
 }
 // one component of src/raytrace.wgsl:80-82: abs(fract(f32(v) / 3141.592653589793))
+// The division is done as x*r, one exact fma residual and one fma correction (r = the f32 nearest 1/c). For every f32
+// an unsigned 32-bit integer can convert to (0 and everything in [1, 2^32]) this is bit for bit the correctly rounded
+// x / c; tools/verify_div_const.c checks all of them (tests/test_oracle.py runs it).
 PT_DEV float rand_component(uint32_t v) {
-    float q = pt_div((float)v, 3141.592653589793f);
+    const float c = 3141.592653589793f, r = 1.0f / 3141.592653589793f;
+    const float x = (float)v;
+    const float q0 = x * r;
+    const float q = __builtin_fmaf(__builtin_fmaf(-c, q0, x), r, q0);
     return __builtin_fabsf(q - __builtin_floorf(q));
 }

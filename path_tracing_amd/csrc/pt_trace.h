@@ -27,8 +27,17 @@ struct HitInfo {
     float u, v;  // hit_record.uv
 };
 
+#ifdef PT_EXEC_COUNTS
+// debug build: how often the wave executes each major block (the first active lane counts)
+#define PT_COUNT(cnt, k) do { if ((uint32_t)(threadIdx.x & 63) == (uint32_t)__builtin_ctzll(__ballot(1))) (cnt).exec[k]++; } while (0)
+#else
+#define PT_COUNT(cnt, k) do { } while (0)
+#endif
 struct LaneCounters {
     uint32_t xforms, box_tests, tri_tests, shades, hits;
+#ifdef PT_EXEC_COUNTS
+    uint32_t exec[16];
+#endif
     uint32_t passes;  // wave-uniform: object-test passes the wave made in its last closest_hit (a measure of how expensive its rays are)
 };
 
@@ -199,6 +208,7 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                 !slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn))
                 return;
             for (uint32_t i = 0; i < n; ++i) {
+                PT_COUNT(cnt, 10);
                 const DTri* T = &sc.tris[tri_first + i];
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
             }
@@ -209,6 +219,7 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
             });
         }
         if (changed) {
+            PT_COUNT(cnt, 11);
             const float t_aabb = hit_box_exact(me->bmin, me->bmax, lo, ld);   // reference :77-80
             if (!(t_aabb < PT_T_MIN)) best = cand;
         }
@@ -289,6 +300,7 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
         float near_t = PT_T_MAX;  // closest hit, and the others are then culled by distance
         if (cull) {
             for (uint32_t k = 0; k < m; ++k) {
+                PT_COUNT(cnt, 8);
                 const float4 blo = sc.obj_lo[base + k], bhi = sc.obj_hi[base + k];
                 float tn;
                 if (STATS) cnt.box_tests++;
@@ -304,6 +316,7 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
         bool first = cull;
         while (__any(mask != 0)) {
             cnt.passes++;
+            PT_COUNT(cnt, 9);
             if (mask != 0) {
                 const uint32_t k = first ? near_k : (uint32_t)__builtin_ctz(mask);
                 first = false;

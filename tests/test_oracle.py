@@ -195,3 +195,15 @@ def test_oracle_rejects_bad_indices():
     scene.objects["mesh"][0] = 99
     with pytest.raises(RuntimeError):
         oracle_render(scene, scene.frame())
+
+
+def test_division_by_the_rng_constant_as_done_on_the_gpu(tmp_path):
+    """The HIP rand() divides by 3141.59... with a multiply and two fmas; tools/verify_div_const.c proves, over every
+    f32 a u32 can convert to, that this is the correctly rounded division the restatement performs."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "verify_div_const"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", str(root / "tools" / "verify_div_const.c"), "-o", str(exe), "-lm"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "268435458 values, 0 mismatches" in r.stdout, r.stdout
