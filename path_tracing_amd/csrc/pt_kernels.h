@@ -286,12 +286,12 @@ __global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__
     const uint32_t c = blockIdx.x * 4u + wave;
     if (c * PT_CHUNK >= total) return;
     const uint32_t i = c * PT_CHUNK + lane;
-    uint32_t v = (i < total) ? cost[i] : 0u;
+    uint32_t v = (i < total) ? min(cost[i], 1u << 24) : 0u;   // (clamped: 64 of them are summed in 32 bits)
     uint32_t n = (i < total) ? 1u : 0u;
     for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); n += __shfl_xor(n, off, 64); }
     if (lane == 0) {
-        const uint32_t bin = (v * 8u) / (n * samples);
-        chunk_bin[c] = bin < PT_COST_BINS ? bin : PT_COST_BINS - 1u;
+        const unsigned long long bin = ((unsigned long long)v * 8ull) / ((unsigned long long)n * samples);
+        chunk_bin[c] = bin < PT_COST_BINS ? (uint32_t)bin : PT_COST_BINS - 1u;
     }
 }
 __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict__ chunk_bin, const DCounters* __restrict__ counters,
