@@ -703,6 +703,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     if ((uint64_t)f->width * f->height > (1ull << 28)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: frame larger than 2^28 pixels");
     const uint32_t pc = f->part_count ? f->part_count : 1u;
     if (f->part_index >= pc) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: part_index >= part_count");
+    if (f->settings.samples > (1u << 30)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: more than 2^30 samples per pixel");
     // This frame's record replaces the one of the frame before the previous one, which has to be complete; the
     // previous frame may still be running (same stream: its kernels come first). Anything that is not plain
     // back-to-back rendering on one stream waits for everything.
