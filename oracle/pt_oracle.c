@@ -32,9 +32,10 @@
  *     M*(v,1) adds M[3][i] last
  *   - a + b*s    = fma(b,s,a) component-wise; mix(a,b,t) = fma(b,t, a*(1-t))
  *   - reflect(I,N) = fma(-(2*dot(N,I)), N, I)
- *   - normalize(v) = v * (1 / sqrt(dot(v,v))) with correctly rounded sqrt and divide
- *     (one reciprocal and three multiplies, the form GPU compilers emit; within WGSL's
- *     accuracy bound for normalize)
+ *   - normalize(v) = v * inverseSqrt(dot(v,v)), inverseSqrt(d) by a fixed recipe:
+ *     y = bits(0x5f375a86 - (bits(d) >> 1)); three times y = y * fma(-((0.5*d)*y), y, 1.5)
+ *     (at most 1.92 ulp from exact for d in [2^-100, 2^100], inside the 2 ulp WGSL allows
+ *     inverseSqrt; GPUs running the reference use a hardware approximation here)
  *   - min/max = fminf/fmaxf; u32(f) truncates and saturates (NaN -> 0)
  *   - sin/cos  : Cody-Waite reduction by pi/2 + degree-7/8 polynomials (below)
  *   - pow(x,5) = ((x*x)*(x*x))*x
@@ -99,8 +100,21 @@ static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
 static inline v3 madd3(v3 a, v3 b, float s) { /* a + b*s */
     return V3(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z));
 }
+/* inverseSqrt by a fixed recipe (see the numerical policy above) */
+static inline float rsqrt_fixed(float d) {
+    union { float f; uint32_t u; } c;
+    c.f = d;
+    c.u = 0x5f375a86u - (c.u >> 1);
+    float y = c.f;
+    const float hd = 0.5f * d;
+    y = y * fmaf(-(hd * y), y, 1.5f);
+    y = y * fmaf(-(hd * y), y, 1.5f);
+    y = y * fmaf(-(hd * y), y, 1.5f);
+    return y;
+}
+float pto_rsqrt(float d) { return rsqrt_fixed(d); }
 static inline v3 normalize3(v3 a) {
-    float r = 1.0f / sqrtf(dot3(a, a));
+    float r = rsqrt_fixed(dot3(a, a));
     return V3(a.x * r, a.y * r, a.z * r);
 }
 static inline v3 xform_dir(const float* m, v3 v) {

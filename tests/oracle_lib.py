@@ -56,6 +56,8 @@ def load_oracle():
     lib.pto_pcg3d.argtypes = [C.c_void_p]
     lib.pto_rand.argtypes = [C.c_void_p, C.c_void_p]
     lib.pto_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.pto_rsqrt.argtypes = [C.c_float]
+    lib.pto_rsqrt.restype = C.c_float
     lib.pto_num_threads.restype = C.c_int
     _lib = lib
     return lib

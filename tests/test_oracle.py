@@ -207,3 +207,24 @@ def test_division_by_the_rng_constant_as_done_on_the_gpu(tmp_path):
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", str(root / "tools" / "verify_div_const.c"), "-o", str(exe), "-lm"], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "268435458 values, 0 mismatches" in r.stdout, r.stdout
+
+
+def test_fixed_recipe_inverse_sqrt_accuracy():
+    """normalize() uses an inverse square root made of a fixed sequence of f32 operations; it has to stay inside the
+    2 ulp WGSL allows inverseSqrt (worst case over every f32 in [2^-100, 2^100] is 1.92 ulp; here: a sample)."""
+    from tests.oracle_lib import load_oracle
+    lib = load_oracle()
+    g = np.random.Generator(np.random.PCG64(7))
+    d = np.concatenate([np.exp2(g.uniform(-100, 100, 20000)), g.uniform(0.25, 4.0, 20000), [1.0, 2.0, 0.5, 3.0, 1e-30, 1e30]]).astype(np.float32)
+    got = np.array([lib.pto_rsqrt(float(x)) for x in d], dtype=np.float32)
+    exact = 1.0 / np.sqrt(d.astype(np.float64))
+    ulp = np.spacing(exact.astype(np.float32)).astype(np.float64)
+    err = np.abs(got.astype(np.float64) - exact) / ulp
+    assert err.max() <= 2.0, err.max()
+    # the recipe itself, restated with numpy f32 operations (every product and sum rounded to f32, the fma exact)
+    y = (np.uint32(0x5f375a86) - (d.view(np.uint32) >> np.uint32(1))).view(np.float32)
+    hd = np.float32(0.5) * d
+    for _ in range(3):
+        t = (hd * y).astype(np.float32)
+        y = (y * (1.5 - t.astype(np.float64) * y.astype(np.float64)).astype(np.float32)).astype(np.float32)
+    assert np.array_equal(y.view(np.uint32), got.view(np.uint32))
