@@ -59,6 +59,7 @@ struct PathParams {
     uint32_t bounces, samples;
     uint32_t chunk;       // path numbers a wave takes from the work counter at a time (multiple of 64)
     uint32_t refill_min;  // a wave hands out new pixels only when at least this many of its lanes are idle (1..64)
+    uint32_t walk_quota;    // PT_MODE_TLAS: lanes that have to finish their walk before a round's trace step ends (1..64)
     uint32_t n_sweeps;      // the samples of a pixel are run in this many consecutive slices (1..PT_MAX_SWEEPS)
     uint32_t sweep_end[8];  // slice j runs samples [sweep_end[j-1], sweep_end[j]); sweep_end[n_sweeps-1] == samples
 };
@@ -398,6 +399,10 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0);
     HitInfo h;
     h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
+    // PT_MODE_TLAS: a lane's TLAS walk survives the rounds of the loop below (see bvh_walk_resume)
+    WalkState ws = {PT_WALK_DONE, 0};
+    Best wb;
+    wb.t = PT_T_MAX; wb.obj = PT_NONE; wb.tri = PT_NONE; wb.u = 0.0f; wb.v = 0.0f;
     bool exhausted = false;  // wave-uniform: the work queue has run out
     bool waiting = false;    // wave-uniform: holding an item whose chunk is not ready yet
     uint32_t first_entry = 0xFFFFFFFFu, n_chunks = 0;  // STATS only
@@ -632,6 +637,11 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 } else {
                     st = PT_ST_TRACE;
                     pending = false;
+                    if (MODE == PT_MODE_TLAS) {   // a new walk starts at the root
+                        ws.node = (sc.tlas_root == PT_NONE) ? PT_WALK_DONE : sc.tlas_root;
+                        ws.sp = 0;
+                        wb.t = PT_T_MAX; wb.obj = PT_NONE; wb.tri = PT_NONE; wb.u = 0.0f; wb.v = 0.0f;
+                    }
                 }
             }
         }
@@ -642,7 +652,25 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             n_rounds++;
             lane_rounds += (unsigned long long)__popcll(__ballot(st == PT_ST_TRACE));
         }
-        if (__any(st == PT_ST_TRACE)) {
+        if (MODE == PT_MODE_TLAS) {
+            // Lanes walk the TLAS until pp.walk_quota of them are through; those get their hit record and go back to
+            // shading in the next round while the others' walks continue where they stopped. With incoherent rays
+            // the walks of a wave differ in length several times over; waiting for the longest one every round left
+            // four lanes in five idle.
+            if (__any(st == PT_ST_TRACE)) {
+                const bool tracing = st == PT_ST_TRACE;
+                const SlabRay sr = world_slab_ray(rpos, rdir);
+                bvh_walk_resume<STATS, PT_BURST_TLAS>(sc.tlas_nodes, sr, wb.t, stk, ws, pp.walk_quota, cnt,
+                                                      [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, rpos, rdir, wb, stk, sp, cnt); });
+                if (tracing && ws.node == PT_WALK_DONE) {
+                    nrays++;
+                    lane_rays++;
+                    if (STATS && wb.obj != PT_NONE) cnt.hits++;
+                    h = finalize_hit(sc, rpos, rdir, wb);
+                    st = PT_ST_SHADE;
+                }
+            }
+        } else if (__any(st == PT_ST_TRACE)) {
             const bool tracing = st == PT_ST_TRACE;
             Best b;
             cnt.passes = 0;

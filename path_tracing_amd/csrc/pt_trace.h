@@ -138,8 +138,12 @@ PT_DEV bool slab_test(const SlabRay& s, float4 lo, float4 hi, float tmax, float&
 // expensive leaf code (object or triangle test) running with as many lanes as possible. The descent is cut after
 // BURST nodes: with incoherent rays a few lanes on long descents would otherwise hold back every lane that
 // already has its leaf. Measured best: 2 where a leaf is one triangle test, 16 where it is a whole object test.
+#ifndef PT_BURST_BLAS
 #define PT_BURST_BLAS 2
+#endif
+#ifndef PT_BURST_TLAS
 #define PT_BURST_TLAS 16
+#endif
 // `tmax` is read through the reference every time, so leaves that shorten the ray tighten the culling at once.
 #define PT_WALK_DONE 0x7FFFFFFFu
 template <bool STATS, int BURST, class LeafFn>
@@ -173,6 +177,53 @@ PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t bias, uint32_t 
             node = (sp > sp0) ? stk.get(--sp) : PT_WALK_DONE;
         }
     }
+}
+
+// The same walk in resumable form, for kernels that keep a lane's walk alive across rounds of their main loop: the
+// state is (current node, stack height); the stack itself stays in the lane's LDS column. The call returns when
+// every lane is done or when at least `quota` of the lanes that were walking at entry have finished, so that those
+// can go on (shade, take a new ray) instead of idling until the longest walk of the wave ends.
+struct WalkState {
+    uint32_t node;  // PT_WALK_DONE: no walk in progress
+    int sp;
+};
+template <bool STATS, int BURST, class LeafFn>
+PT_DEV void bvh_walk_resume(const BvhNode* __restrict__ nodes, const SlabRay& sr, const float& tmax, LdsStack stk, WalkState& ws,
+                            uint32_t quota, LaneCounters& cnt, LeafFn leaf) {
+    uint32_t node = ws.node;
+    int sp = ws.sp;
+    const uint32_t walking = (uint32_t)__popcll(__ballot(node != PT_WALK_DONE));
+    const uint32_t stop_at = walking > quota ? walking - quota : 0u;   // leave the loop when this many (or fewer) still walk
+    for (;;) {
+        const uint32_t still = (uint32_t)__popcll(__ballot(node != PT_WALK_DONE));
+        if (still <= stop_at) break;
+        for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
+            const BvhNode* N = &nodes[node];
+            float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
+            if (STATS) cnt.box_tests += 2;
+            float tl, tr;
+            bool hit_l = slab_test(sr, ll, hl, tmax, tl);
+            bool hit_r = slab_test(sr, lr, hr, tmax, tr);
+            uint32_t cl = __float_as_uint(ll.w), cr = __float_as_uint(lr.w);
+            if (hit_l && hit_r) {
+                bool left_first = tl <= tr;
+                stk.put(sp++, left_first ? cr : cl);
+                node = left_first ? cl : cr;
+            } else if (hit_l) {
+                node = cl;
+            } else if (hit_r) {
+                node = cr;
+            } else {
+                node = (sp > 0) ? stk.get(--sp) : PT_WALK_DONE;
+            }
+        }
+        if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
+            leaf(node & ~PT_LEAF_BIT, sp);
+            node = (sp > 0) ? stk.get(--sp) : PT_WALK_DONE;
+        }
+    }
+    ws.node = node;
+    ws.sp = sp;
 }
 
 // hit_mesh for one object (reference src/query.wgsl:66-125). Each lane brings its own object; lanes whose objects

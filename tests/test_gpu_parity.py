@@ -267,7 +267,7 @@ def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
 
     run(3)   # (the glb scene: from the second frame on its big mesh's BLAS is staged in LDS)
     for env in ({"PT_AMD_SWEEPS": "1"}, {"PT_AMD_SWEEPS": "8"}, {"PT_AMD_NO_COST_HINTS": "1"}, {"PT_AMD_REFILL_MIN": "1"},
-                {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}, {"PT_AMD_NO_LDS_BLAS": "1"}):
+                {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}, {"PT_AMD_NO_LDS_BLAS": "1"}, {"PT_AMD_WALK_QUOTA": "1"}, {"PT_AMD_WALK_QUOTA": "64"}):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
