@@ -160,6 +160,11 @@ def main():
             buf.mul_(1.0 / world)
             reduced[k].record(comm_stream)
 
+    # one untimed frame per context: allocations, and the ray counts the next frame's schedule is derived from
+    for k in range(F):
+        ctxs[k].render_device(frame, bufs[k].data_ptr(), streams[k].cuda_stream)
+    torch.cuda.synchronize(device)
+
     # detailed work counters from one untimed pass (slower kernel variant)
     ctx.set_stats_detail(True)
     ctx.render_device(frame, out.data_ptr(), stream.cuda_stream)
