@@ -8,6 +8,8 @@ scene and image resident in HBM. For N > 1 (launched by torch.distributed.run, o
 rank renders the same frame as an independent virtual frame (its own `time`, hence its own per-pixel
 seeds, exactly how the reference de-correlates successive frames) and the radiance buffers are summed
 with one RCCL all-reduce per step: N x 64 spp per step, per-GPU work fixed (weak scaling).
+`--multi-gpu tiles` instead splits the 8x8 tiles of ONE frame over the ranks (all-reduce = gather, image
+bit-identical to the one-GPU image, strong scaling).
 
 Frames are kept in flight (--frames-in-flight, default 2): that many contexts take the frames in turn on their own
 streams, so the start of a frame overlaps the tail of the previous one; results are those of one context.
@@ -90,6 +92,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="contexts that take the frames in turn (1: strictly one frame at a time)")
+    ap.add_argument("--multi-gpu", default="virtual_frames", choices=["virtual_frames", "tiles"],
+                    help="N > 1: every GPU renders its own virtual frame (N x spp, weak scaling) or a share of the tiles of one frame (strong scaling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path with every rank on GPU 0")
     args = ap.parse_args()
 
@@ -118,7 +122,13 @@ def main():
     scene = make()
     if args.spp:
         scene.samples = args.spp
-    frame = scene.frame(time=virtual_frame_time(rank))
+    tiles = args.multi_gpu == "tiles" and world > 1
+    if tiles:
+        # exact split: 8x8 tiles dealt round-robin to the ranks, all-reduce(sum) of the disjoint images = gather;
+        # the result is bit-identical to the one-GPU image (total work fixed: strong scaling)
+        frame = scene.frame(time=0.0, part_index=rank, part_count=world)
+    else:
+        frame = scene.frame(time=virtual_frame_time(rank))
     W, H = frame.width, frame.height
 
     # Frames in flight: F contexts (the scene arrays are small), each with its own stream and image buffer, take
@@ -157,7 +167,8 @@ def main():
                 host = buf.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
                 buf.copy_(host)
-            buf.mul_(1.0 / world)
+            if not tiles:
+                buf.mul_(1.0 / world)
             reduced[k].record(comm_stream)
 
     # one untimed frame per context: allocations, and the ray counts the next frame's schedule is derived from
@@ -245,13 +256,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if tiles else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "scene": scene.name, "width": W, "height": H, "spp_per_gpu": scene.samples,
                        "bounces": scene.bounces, "objects": int(scene.objects.size), "triangles": scene.n_triangles,
-                       "multi_gpu": "one virtual frame per GPU + RCCL all-reduce(sum) of the f32 radiance buffer" if world > 1 else "single GPU",
+                       "multi_gpu": ("8x8 tiles round-robin over the GPUs + RCCL all-reduce(sum) as gather" if tiles else
+                                     "one virtual frame per GPU + RCCL all-reduce(sum) of the f32 radiance buffer") if world > 1 else "single GPU",
                        "frames_in_flight": F},
             "rays_per_step": rays_total,
             "rays_definition": "closest-hit queries executed; the primary ray of a pixel is identical for all of its samples "
