@@ -114,7 +114,11 @@ static inline float rsqrt_fixed(float d) {
 }
 float pto_rsqrt(float d) { return rsqrt_fixed(d); }
 static inline v3 normalize3(v3 a) {
+#ifdef PTO_IEEE_NORMALIZE /* alternative evaluation, only to measure how far apart two legal evaluations of normalize() are */
+    float r = 1.0f / sqrtf(dot3(a, a));
+#else
     float r = rsqrt_fixed(dot3(a, a));
+#endif
     return V3(a.x * r, a.y * r, a.z * r);
 }
 static inline v3 xform_dir(const float* m, v3 v) {

@@ -228,3 +228,31 @@ def test_fixed_recipe_inverse_sqrt_accuracy():
         t = (hd * y).astype(np.float32)
         y = (y * (1.5 - t.astype(np.float64) * y.astype(np.float64)).astype(np.float32)).astype(np.float32)
     assert np.array_equal(y.view(np.uint32), got.view(np.uint32))
+
+
+def test_normalize_recipe_against_the_correctly_rounded_evaluation(tmp_path):
+    """How much the choice of normalize() evaluation matters: the restatement built with sqrt and division
+    (-DPTO_IEEE_NORMALIZE) gives the same primary hits and, on these small frames, images within 1e-6 relative RMSE
+    of the fixed-recipe build (the paths are the same; a flipped decision would desynchronise a pixel's RNG stream)."""
+    import subprocess
+    from pathlib import Path
+    import tests.oracle_lib as ol
+    from path_tracing_amd import scenes
+    root = Path(__file__).resolve().parent.parent
+    alt = tmp_path / "libpt_oracle_ieee.so"
+    subprocess.run(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-mavx2", "-fopenmp", "-fPIC", "-shared",
+                    "-DPTO_IEEE_NORMALIZE", f"-I{root / 'include'}", "-o", str(alt), str(root / "oracle" / "pt_oracle.c"), "-lm"], check=True)
+    results = {}
+    saved = (ol._lib, ol.ORACLE_SO)
+    try:
+        for tag, so in (("recipe", saved[1]), ("ieee", alt)):
+            ol._lib, ol.ORACLE_SO = None, Path(so)
+            for name, sc in (("cornell", scenes.cornell_box(96, 96, 8, 10)), ("boxes", scenes.boxes(160, 90, 16, 10))):
+                results[tag, name] = ol.oracle_render(sc, sc.frame())
+    finally:
+        ol._lib, ol.ORACLE_SO = None, saved[1]
+    for name in ("cornell", "boxes"):
+        a, b = results["recipe", name], results["ieee", name]
+        assert np.array_equal(a["primary_flat_id"], b["primary_flat_id"])
+        x, y = a["image"][..., :3].astype(np.float64), b["image"][..., :3].astype(np.float64)
+        assert np.sqrt(((x - y) ** 2).sum() / (y ** 2).sum()) <= 1e-6
