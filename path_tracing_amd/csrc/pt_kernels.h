@@ -276,7 +276,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
 // chunk numbers by descending bin with a counting sort and reports how many chunks count as expensive.
 #define PT_CHUNK 64u
 #define PT_COST_BINS 32u
+#ifndef PT_HEAVY_BIN
 #define PT_HEAVY_BIN 2u   // chunks from this bin up (0.25 extra rays per sample) are run in one piece, first
+#endif
 struct ChunkOrderInfo {
     uint32_t n_chunks, n_heavy;
 };
