@@ -654,6 +654,9 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             n_rounds++;
             lane_rounds += (unsigned long long)__popcll(__ballot(st == PT_ST_TRACE));
         }
+        // No lane holds a hit that still has to be shaded at this point: say so, or the nine registers of the old
+        // record stay occupied all through the closest-hit code.
+        h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
         if (MODE == PT_MODE_TLAS) {
             // Lanes walk the TLAS until pp.walk_quota of them are through; those get their hit record and go back to
             // shading in the next round while the others' walks continue where they stopped. With incoherent rays
