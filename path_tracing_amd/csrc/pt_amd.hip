@@ -816,7 +816,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         pp.chunk = ctx->chunk_pixels;
         // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
         pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
-        const size_t lds = ((size_t)4 * (depth + PT_LANE_SLOTS) * 64 + 4 * PT_SCHED_WORDS) * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
+        const size_t lds = ((size_t)4 * (depth + lane_slots(mode)) * 64 + 4 * PT_SCHED_WORDS) * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
         using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, LdsBlas, PathParams, uint32_t, const PathRec*, PathCarry*, uint32_t*, const uint32_t*, const ChunkOrderInfo*, float4*,
                                  uint32_t*, DCounters*, uint4*);
         static const PathsFn ptable[4][2] = {{k_paths<PT_MODE_LIST, false>, k_paths<PT_MODE_LIST, true>},

@@ -347,6 +347,11 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
 #define PT_SLOT_ENTRY 16     // list entry; bit 31: this sweep ends the pixel
 #define PT_SLOT_PIX 17       // pixel number
 #define PT_LANE_SLOTS 18
+// PT_MODE_LDS only (small scenes leave the room): the part of the scatter evaluation of the primary hit that is the
+// same for every sample of the pixel (BrdfFrame: tangent frame, reflected ray, N.V, albedo), 13 more words per lane
+#define PT_SLOT_FRAME 18
+#define PT_LANE_SLOTS_LDS 31
+__host__ __device__ constexpr uint32_t lane_slots(int mode) { return mode == PT_MODE_LDS ? PT_LANE_SLOTS_LDS : PT_LANE_SLOTS; }
 // per-wave LDS words (scheduling state)
 #define PT_SCHED_NEXT 0      // list entries of the current item not handed to lanes yet: [next, end)
 #define PT_SCHED_END 1
@@ -365,17 +370,18 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                                                                     float4* __restrict__ out, uint32_t* __restrict__ aux_rays,
                                                                     DCounters* __restrict__ counters, uint4* __restrict__ wave_log) {
     PT_SCENE_VIEW_FROM_PARAMS()
-    // [4 waves][stack_depth][64 lanes] stacks, [4 waves][PT_LANE_SLOTS][64 lanes], [4 waves][PT_SCHED_WORDS], staged scene
+    // [4 waves][stack_depth][64 lanes] stacks, [4 waves][lane_slots(MODE)][64 lanes], [4 waves][PT_SCHED_WORDS], staged scene
+    constexpr uint32_t SLOTS = lane_slots(MODE);
     extern __shared__ uint32_t s_mem[];
-    const uint32_t lds_fixed = 4 * (stack_depth + PT_LANE_SLOTS) * 64 + 4 * PT_SCHED_WORDS;
+    const uint32_t lds_fixed = 4 * (stack_depth + SLOTS) * 64 + 4 * PT_SCHED_WORDS;
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + lds_fixed);
     if (MODE == PT_MODE_LIST_LB) stage_blas_in_lds(sc, lb, s_mem + lds_fixed);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;
     stk.base = &s_mem[wave * stack_depth * 64 + lane];
-    uint32_t* slot_u = &s_mem[4 * stack_depth * 64 + wave * PT_LANE_SLOTS * 64 + lane];  // slot[k * 64]
+    uint32_t* slot_u = &s_mem[4 * stack_depth * 64 + wave * SLOTS * 64 + lane];  // slot[k * 64]
     float* slot = reinterpret_cast<float*>(slot_u);
-    uint32_t* sched = &s_mem[4 * (stack_depth + PT_LANE_SLOTS) * 64 + wave * PT_SCHED_WORDS];
+    uint32_t* sched = &s_mem[4 * (stack_depth + SLOTS) * 64 + wave * PT_SCHED_WORDS];
     if (lane == 0) {
         sched[PT_SCHED_NEXT] = 0; sched[PT_SCHED_END] = 0;
         sched[PT_SCHED_ITEM] = PT_NONE; sched[PT_SCHED_REPORT] = PT_NONE;
@@ -521,6 +527,19 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                         slot_u[PT_SLOT_LEFT * 64] = sw_len & 0x7FFFFFFFu;
                         slot_u[PT_SLOT_ENTRY * 64] = entry | (sw_len & 0x80000000u);
                         slot_u[PT_SLOT_PIX * 64] = __float_as_uint(ra.x);
+                        if (MODE == PT_MODE_LDS) {
+                            // the sample-independent part of scattering off the primary hit, once per pixel and sweep
+                            const DMaterial pm = sc.materials[sc.objects[h.obj].mat];
+                            v3 N = h.n;
+                            if (pm.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, pm.normal_map_texture, h.u, h.v));
+                            const BrdfFrame f = brdf_frame(sc, rdir, N, h.u, h.v, pm);
+                            float* fs = slot + PT_SLOT_FRAME * 64;
+                            fs[0 * 64] = f.tt.x; fs[1 * 64] = f.tt.y; fs[2 * 64] = f.tt.z;
+                            fs[3 * 64] = f.bb.x; fs[4 * 64] = f.bb.y; fs[5 * 64] = f.bb.z;
+                            fs[6 * 64] = f.refl_om.x; fs[7 * 64] = f.refl_om.y; fs[8 * 64] = f.refl_om.z;
+                            fs[9 * 64] = f.NdotV;
+                            fs[10 * 64] = f.albedo.x; fs[11 * 64] = f.albedo.y; fs[12 * 64] = f.albedo.z;
+                        }
                         bounce = 0;
                         ray_color = V3(1, 1, 1);
                         color = V3(0, 0, 0);
@@ -626,7 +645,24 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
                 v3 ndir, bcol;
                 if (STATS) cnt.shades++;
-                calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
+                if (MODE == PT_MODE_LDS) {
+                    // bounce 0 scatters off the primary hit: its frame is in LDS; waves whose lanes all restart a
+                    // sample together (the common case) skip the frame computation altogether
+                    BrdfFrame f;
+                    if (bounce == 0u) {
+                        const float* fs = slot + PT_SLOT_FRAME * 64;
+                        f.tt = V3(fs[0 * 64], fs[1 * 64], fs[2 * 64]);
+                        f.bb = V3(fs[3 * 64], fs[4 * 64], fs[5 * 64]);
+                        f.refl_om = V3(fs[6 * 64], fs[7 * 64], fs[8 * 64]);
+                        f.NdotV = fs[9 * 64];
+                        f.albedo = V3(fs[10 * 64], fs[11 * 64], fs[12 * 64]);
+                    } else {
+                        f = brdf_frame(sc, rdir, N, h.u, h.v, m);
+                    }
+                    brdf_sample(rng, rdir, N, m.roughness, f, ndir, bcol);
+                } else {
+                    calculate_brdf(sc, rng, rdir, N, h.u, h.v, m, ndir, bcol);
+                }
                 rdir = ndir;
                 rpos = madd3(h.p, rdir, 0.001f);
                 ray_color = mul3(ray_color, bcol);

@@ -458,17 +458,36 @@ PT_DEV v3 sample_texture(const SceneView& sc, uint32_t idx, float u, float v) {
 // bevy_pbr::lighting::F_Schlick with f0 = 1
 PT_DEV float f_schlick_1(float f90, float u) { return pt_fma(f90 - 1.0f, pt_pow5(1.0f - u), 1.0f); }
 
-// src/raytrace.wgsl:157-203. N is hit_record.n after the normal-map multiply.
-PT_DEV void calculate_brdf(const SceneView& sc, Rng& rng, v3 ray_dir, v3 N, float hu, float hv, const DMaterial& m,
-                           v3& out_dir, v3& out_color) {
-    // hugues_moller (:102-116)
+// src/raytrace.wgsl:157-203, in two parts. N is hit_record.n after the normal-map multiply.
+// brdf_frame: everything that depends only on the hit and the incoming ray (tangent frame, reflected ray, albedo,
+// N.V): the same for every sample of a pixel when the hit is the primary hit, so k_paths keeps it per pixel.
+// brdf_sample: the part that draws random numbers. calculate_brdf = both, the operations and their order unchanged.
+struct BrdfFrame {
+    v3 tt, bb;     // hugues_moller(N) columns 0 and 1 (:102-116)
+    v3 refl_om;    // normalize(reflect(ray_dir, N)) * (1 - roughness)
+    float NdotV;
+    v3 albedo;
+};
+PT_DEV BrdfFrame brdf_frame(const SceneView& sc, v3 ray_dir, v3 N, float hu, float hv, const DMaterial& m) {
+    BrdfFrame f;
     float ax = __builtin_fabsf(N.x), ay = __builtin_fabsf(N.y), az = __builtin_fabsf(N.z);
     v3 tt;
     if (ax <= ay && ax <= az) tt = V3(0.0f, -N.z, N.y);
     else if (ay <= ax && ay <= az) tt = V3(-N.z, 0.0f, N.x);
     else tt = V3(-N.y, N.x, 0.0f);
-    tt = normalize3(tt);
-    v3 bb = normalize3(cross3(N, tt));
+    f.tt = normalize3(tt);
+    f.bb = normalize3(cross3(N, f.tt));
+    float k2 = 2.0f * dot3(N, ray_dir);
+    v3 reflection_ray = normalize3(madd3(ray_dir, N, -k2));
+    float om = 1.0f - m.roughness;
+    f.refl_om = V3(reflection_ray.x * om, reflection_ray.y * om, reflection_ray.z * om);
+    v3 albedo = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    if (m.albedo_texture != PT_NONE) albedo = mul3(albedo, sample_texture(sc, m.albedo_texture, hu, hv));
+    f.albedo = albedo;
+    f.NdotV = pt_max(dot3(N, neg3(ray_dir)), 0.0001f);
+    return f;
+}
+PT_DEV void brdf_sample(Rng& rng, v3 ray_dir, v3 N, float rough_in, const BrdfFrame& f, v3& out_dir, v3& out_color) {
     // cosine_sample (:88-95)
     pcg3d(rng);
     float r0 = rand_component(rng.x), r1 = rand_component(rng.y);
@@ -478,29 +497,24 @@ PT_DEV void calculate_brdf(const SceneView& sc, Rng& rng, v3 ray_dir, v3 N, floa
     float sn, cs;
     pt_sincos(phi, sn, cs);
     v3 c = V3(sin_theta * cs, sin_theta * sn, cos_theta);
-    v3 lam = V3(pt_fma(N.x, c.z, pt_fma(bb.x, c.y, tt.x * c.x)), pt_fma(N.y, c.z, pt_fma(bb.y, c.y, tt.y * c.x)),
-                pt_fma(N.z, c.z, pt_fma(bb.z, c.y, tt.z * c.x)));
+    v3 lam = V3(pt_fma(N.x, c.z, pt_fma(f.bb.x, c.y, f.tt.x * c.x)), pt_fma(N.y, c.z, pt_fma(f.bb.y, c.y, f.tt.y * c.x)),
+                pt_fma(N.z, c.z, pt_fma(f.bb.z, c.y, f.tt.z * c.x)));
     v3 lambertian_ray = normalize3(lam);
-    float k2 = 2.0f * dot3(N, ray_dir);
-    v3 reflection_ray = normalize3(madd3(ray_dir, N, -k2));
-    float rough_in = m.roughness;
-    float om = 1.0f - rough_in;
-    v3 L = V3(pt_fma(lambertian_ray.x, rough_in, reflection_ray.x * om),
-              pt_fma(lambertian_ray.y, rough_in, reflection_ray.y * om),
-              pt_fma(lambertian_ray.z, rough_in, reflection_ray.z * om));
-
-    v3 albedo = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
-    if (m.albedo_texture != PT_NONE) albedo = mul3(albedo, sample_texture(sc, m.albedo_texture, hu, hv));
-
+    v3 L = V3(pt_fma(lambertian_ray.x, rough_in, f.refl_om.x), pt_fma(lambertian_ray.y, rough_in, f.refl_om.y),
+              pt_fma(lambertian_ray.z, rough_in, f.refl_om.z));
     v3 V = neg3(ray_dir);
-    float NdotV = pt_max(dot3(N, V), 0.0001f);
     float cr = pt_min(pt_max(rough_in, 0.089f), 1.0f);
     float roughness = cr * cr;
     v3 H = normalize3(add3(L, V));
     float NdotL = pt_saturate(dot3(N, L));
     float LdotH = pt_saturate(dot3(L, H));
     float f90 = pt_fma((2.0f * roughness) * LdotH, LdotH, 0.5f);
-    float fd = (f_schlick_1(f90, NdotL) * f_schlick_1(f90, NdotV)) * (1.0f / PT_PI);
+    float fd = (f_schlick_1(f90, NdotL) * f_schlick_1(f90, f.NdotV)) * (1.0f / PT_PI);
     out_dir = L;
-    out_color = scale3(scale3(albedo, fd), PT_PI);
+    out_color = scale3(scale3(f.albedo, fd), PT_PI);
+}
+PT_DEV void calculate_brdf(const SceneView& sc, Rng& rng, v3 ray_dir, v3 N, float hu, float hv, const DMaterial& m,
+                           v3& out_dir, v3& out_color) {
+    const BrdfFrame f = brdf_frame(sc, ray_dir, N, hu, hv, m);
+    brdf_sample(rng, ray_dir, N, m.roughness, f, out_dir, out_color);
 }
