@@ -624,6 +624,15 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 if (h.obj != PT_NONE) {
                     PT_COUNT(cnt, 2);
                     stop = add_emitted();
+                    // Scatters whose only surviving effect is the one random draw of cosine_sample: the hit of a
+                    // path's last segment (the reference still scatters off it, src/raytrace.wgsl:256-260, but the new
+                    // ray is never traced and the throughput never used again), and a scatter that is known to leave
+                    // a throughput of exactly zero (src/raytrace.wgsl:266-269 then ends the path). Only the RNG is
+                    // stepped and the path ends here, in the cheap step, instead of costing the wave a scatter pass.
+                    if (!stop && (bounce + 1u >= bounces || scatter_goes_dark(sc, h, rdir, ray_color))) {
+                        pcg3d(rng);
+                        stop = true;
+                    }
                 } else {
                     color = V3(pt_fma(ray_color.x, pp.sky[0], color.x), pt_fma(ray_color.y, pp.sky[1], color.y),
                                pt_fma(ray_color.z, pp.sky[2], color.z));

@@ -518,3 +518,22 @@ PT_DEV void calculate_brdf(const SceneView& sc, Rng& rng, v3 ray_dir, v3 N, floa
     const BrdfFrame f = brdf_frame(sc, ray_dir, N, hu, hv, m);
     brdf_sample(rng, ray_dir, N, m.roughness, f, out_dir, out_color);
 }
+
+// True only when calculate_brdf at this hit is certain to leave max(ray_color * brdf.color) == 0, so that the path
+// ends on the throughput cutoff (src/raytrace.wgsl:266-269) whatever direction is sampled. brdf.color is
+// (albedo * Fd_Burley) * PI per channel. Fd_Burley is finite whenever N.V is: every other input of it is clamped to
+// [0, 1] (NaNs included) and roughness^2 to [0.089^2, 1]. Then a channel whose albedo or incoming throughput is
+// exactly zero, the other factor being finite and far from overflow, comes out as +-0; three such channels give
+// p = +-0 < EPSILON. Materials with an albedo texture or a normal map take the general path.
+PT_DEV bool scatter_goes_dark(const SceneView& sc, const HitInfo& h, v3 ray_dir, v3 ray_color) {
+    const DMaterial* m = &sc.materials[sc.objects[h.obj].mat];
+    if (m->albedo_texture != PT_NONE || m->normal_map_texture != PT_NONE) return false;
+    const float big = 1.0e30f;
+    const float ax = m->albedo[0], ay = m->albedo[1], az = m->albedo[2];
+    const bool zx = (ax == 0.0f || ray_color.x == 0.0f) && __builtin_fabsf(ax) <= big && __builtin_fabsf(ray_color.x) <= big;
+    const bool zy = (ay == 0.0f || ray_color.y == 0.0f) && __builtin_fabsf(ay) <= big && __builtin_fabsf(ray_color.y) <= big;
+    const bool zz = (az == 0.0f || ray_color.z == 0.0f) && __builtin_fabsf(az) <= big && __builtin_fabsf(ray_color.z) <= big;
+    if (!(zx && zy && zz)) return false;
+    const float NdotV = pt_max(dot3(h.n, neg3(ray_dir)), 0.0001f);
+    return NdotV <= 2.0f;   // (false for NaN) |1 - N.V| <= 1, so both Schlick factors are finite
+}

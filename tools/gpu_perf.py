@@ -21,6 +21,7 @@ sys.path.insert(0, str(ROOT))
 SCENES = {
     "boxes": ("boxes", dict(width=1920, height=1080, samples=64)),
     "cornell": ("cornell", dict(width=512, height=512, samples=16)),
+    "cornell_hd": ("cornell", dict(width=1920, height=1080, samples=64)),
     "glb": ("scene_glb_textured", dict(width=1920, height=1080, samples=16)),
     "inst": ("instanced_boxes", dict(width=1920, height=1080, samples=4)),
 }
