@@ -30,8 +30,11 @@ struct HitInfo {
 #ifdef PT_EXEC_COUNTS
 // debug build: how often the wave executes each major block (the first active lane counts)
 #define PT_COUNT(cnt, k) do { if ((uint32_t)(threadIdx.x & 63) == (uint32_t)__builtin_ctzll(__ballot(1))) (cnt).exec[k]++; } while (0)
+// the same, adding the number of lanes for which `cond` holds
+#define PT_COUNT_LANES(cnt, k, cond) do { const uint32_t n_ = (uint32_t)__popcll(__ballot(cond)); if ((uint32_t)(threadIdx.x & 63) == (uint32_t)__builtin_ctzll(__ballot(1))) (cnt).exec[k] += n_; } while (0)
 #else
 #define PT_COUNT(cnt, k) do { } while (0)
+#define PT_COUNT_LANES(cnt, k, cond) do { } while (0)
 #endif
 struct LaneCounters {
     uint32_t xforms, box_tests, tri_tests, shades, hits;
@@ -198,6 +201,7 @@ PT_DEV void bvh_walk_resume(const BvhNode* __restrict__ nodes, const SlabRay& sr
         const uint32_t still = (uint32_t)__popcll(__ballot(node != PT_WALK_DONE));
         if (still <= stop_at) break;
         for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
+            PT_COUNT(cnt, 8); PT_COUNT_LANES(cnt, 13, true);
             const BvhNode* N = &nodes[node];
             float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
             if (STATS) cnt.box_tests += 2;
@@ -218,6 +222,7 @@ PT_DEV void bvh_walk_resume(const BvhNode* __restrict__ nodes, const SlabRay& sr
             }
         }
         if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
+            PT_COUNT(cnt, 9); PT_COUNT_LANES(cnt, 14, true);
             leaf(node & ~PT_LEAF_BIT, sp);
             node = (sp > 0) ? stk.get(--sp) : PT_WALK_DONE;
         }
@@ -248,22 +253,26 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
         // scene records live in LDS: every lane reads its own mesh and triangles, no grouping by mesh needed
         const DMesh* me = &sc.meshes[mesh_id];
         const uint32_t root = me->blas_root, tri_first = me->tri_first;
+        // (the culling ray is only built where it is used: three reciprocals and a dozen operations that the
+        // two-triangle meshes of a Cornell box never need)
         const float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) + me->max_abs);
-        const SlabRay sr = make_slab_ray(lo, ld, pad);
         if (root == PT_NONE) {
             // no BLAS: the padded mesh box stands in for its root (the same test a BLAS walk starts with)
             const uint32_t n = me->tri_count;
-            float tn;
             if (STATS) cnt.box_tests++;
-            if (n > PT_LOCAL_BOX_MIN_TRIS &&
-                !slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn))
-                return;
+            if (n > PT_LOCAL_BOX_MIN_TRIS) {
+                float tn;
+                const SlabRay sr = make_slab_ray(lo, ld, pad);
+                if (!slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn))
+                    return;
+            }
             for (uint32_t i = 0; i < n; ++i) {
                 PT_COUNT(cnt, 10);
                 const DTri* T = &sc.tris[tri_first + i];
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
             }
         } else {
+            const SlabRay sr = make_slab_ray(lo, ld, pad);
             bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, 0u, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
                 const DTri* T = &sc.tris[tri_first + tri];
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
@@ -298,6 +307,7 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                         slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn);
                     if (__any(inside)) {
                         for (uint32_t i = 0; i < n; ++i) {
+                            PT_COUNT(cnt, 10); PT_COUNT_LANES(cnt, 15, inside);
                             const DTri* T = &sc.tris[tri_first + i];
                             if (inside) changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
                         }
