@@ -127,6 +127,45 @@ def test_materials_zoo_against_oracle(accel):
     assert_same(got, ref["image"], ref["primary_object"], ref["primary_flat_id"], ref["primary_t"].view(np.uint32), ref["ray_count"])
 
 
+def dead_scatter_scene(bounces):
+    """Surfaces whose scatter result is never used: the last segment of a path (small bounce limits) and
+    throughputs that become exactly zero (albedo channels that are exactly 0 meeting each other), next to the
+    cases in which the kernel must NOT take that shortcut: an albedo texture, a normal map, channels that are
+    tiny but not zero, albedo beyond the bound of the shortcut, roughness outside [0, 1]."""
+    b = scenes.SceneBuilder()
+    g = np.random.Generator(np.random.PCG64(11))
+    tex = b.add_texture(np.where(g.uniform(0, 1, 8 * 8 * 3) < 0.5, 0.0, 1.0), 8, 8, 3)   # texels exactly 0 or 1
+    tn = b.add_texture(g.uniform(0.5, 1, 8 * 8 * 3), 8, 8, 3)
+    cube = b.add_mesh(*scenes.cube_mesh(1.0))
+    plane = b.add_mesh(*scenes.plane_mesh((0, 1, 0), 4.0))
+    mats = [b.add_material(albedo=(1, 0, 0), roughness=0.5), b.add_material(albedo=(0, 1, 0), roughness=1.0),
+            b.add_material(albedo=(0, 0, 1), roughness=0.0), b.add_material(albedo=(1e-30, 0, 1e-38), roughness=0.3),
+            b.add_material(albedo=(2e30, 0, 0), roughness=0.7), b.add_material(albedo=(0, 3e15, 0), roughness=3.0),
+            b.add_material(albedo=(1, 1, 0), albedo_texture=tex, roughness=-0.5),
+            b.add_material(albedo=(0, 1, 1), normal_map_texture=tn, roughness=0.2),
+            b.add_material(albedo=(0, 0, 0), emissive=(3, 2, 1))]
+    k = 0
+    for ix in range(3):
+        for iz in range(3):
+            b.add_object(cube, mats[k], scenes.translation(-1.6 + 1.6 * ix, 0.0, -1.6 + 1.6 * iz) @ scenes.rotation_y(0.4 * k) @ scenes.scaling(1.0, 0.6 + 0.2 * k, 1.0))
+            k += 1
+    b.add_object(plane, b.add_material(albedo=(1, 1, 1), roughness=0.4), scenes.translation(0, -0.9, 0))
+    return b.build("dead", scenes.Camera((2.5, 3.0, 4.5), (0, 0, 0)), sky_color=(0.3, 0.4, 0.5), width=96, height=64, samples=6, bounces=bounces)
+
+
+@pytest.mark.parametrize("bounces", [1, 2, 3, 10])
+def test_unused_scatters_against_oracle(bounces):
+    scene = dead_scatter_scene(bounces)
+    frame = scene.frame()
+    ref = oracle_render(scene, frame)
+    for accel in (abi.PT_ACCEL_AUTO, abi.PT_ACCEL_BVH):
+        got = render_all(scene, frame, accel)
+        # (the 2e30 albedo overflows to inf on paths that meet it twice: bits are compared, not an RMSE)
+        assert np.array_equal(got["primary_flat_id"], ref["primary_flat_id"])
+        assert np.array_equal(got["ray_count"], ref["ray_count"])
+        assert np.array_equal(got["image"].view(np.uint32), ref["image"].view(np.uint32)), "image not bit-identical"
+
+
 def test_query_random_rays_against_oracle():
     scene = scenes.instanced_boxes(n_objects=3000, width=8, height=8, samples=1, extent=10.0)
     g = np.random.Generator(np.random.PCG64(99))
