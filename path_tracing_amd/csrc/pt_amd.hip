@@ -681,9 +681,10 @@ int scene_mode(const pt_ctx* ctx, LdsScene* ls) {
     ls->bytes_blas = (uint32_t)sizeof(BvhNode) * ctx->n_blas_nodes;
     ls->bytes_materials = (uint32_t)sizeof(DMaterial) * ctx->n_materials;
     ls->bytes_textures = (uint32_t)sizeof(DTexture) * ctx->n_textures;
-    const uint64_t sum = 2ull * ls->bytes_obj_box + ls->bytes_objects + ls->bytes_meshes + ls->bytes_tris + ls->bytes_attrs +
+    const uint64_t sum = 5ull * ls->bytes_obj_box + ls->bytes_objects + ls->bytes_meshes + ls->bytes_tris + ls->bytes_attrs +
                          ls->bytes_blas + ls->bytes_materials + ls->bytes_textures;
     if (sum > kLdsSceneMaxBytes) return PT_MODE_LIST;
+    ls->off_obj_slab = place(3u * ls->bytes_obj_box);   // 12 floats per object
     ls->off_obj_lo = place(ls->bytes_obj_box);
     ls->off_obj_hi = place(ls->bytes_obj_box);
     ls->off_objects = place(ls->bytes_objects);

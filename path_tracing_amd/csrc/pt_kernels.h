@@ -68,7 +68,7 @@ struct PathParams {
 // Where each scene array sits in the LDS copy (byte offsets from the start of the staged region, multiples of 16)
 // and how many bytes it has. Small scenes only: see lds_scene_layout() on the host side.
 struct LdsScene {
-    uint32_t off_obj_lo, off_obj_hi, off_objects, off_meshes, off_tris, off_attrs, off_blas, off_materials, off_textures;
+    uint32_t off_obj_slab, off_obj_lo, off_obj_hi, off_objects, off_meshes, off_tris, off_attrs, off_blas, off_materials, off_textures;
     uint32_t bytes_obj_box, bytes_objects, bytes_meshes, bytes_tris, bytes_attrs, bytes_blas, bytes_materials, bytes_textures;
     uint32_t total_bytes;
 };
@@ -91,7 +91,18 @@ PT_DEV void stage_scene_in_lds(SceneView& sc, const LdsScene& ls, uint32_t* lds)
     lds_copy16(lds + ls.off_blas / 4, sc.blas_nodes, ls.bytes_blas);
     lds_copy16(lds + ls.off_materials / 4, sc.materials, ls.bytes_materials);
     lds_copy16(lds + ls.off_textures / 4, sc.textures, ls.bytes_textures);
+    {   // world boxes once more, in the (lo, hi, lo, 0)-per-axis form read by slab_test_sel
+        float* slab = reinterpret_cast<float*>(lds + ls.off_obj_slab / 4);
+        const uint32_t n_obj = ls.bytes_obj_box / 16u;
+        for (uint32_t i = threadIdx.x; i < n_obj * 3u; i += blockDim.x) {
+            const uint32_t o = i / 3u, axis = i - o * 3u;
+            const float lo = reinterpret_cast<const float*>(&sc.obj_lo[o])[axis], hi = reinterpret_cast<const float*>(&sc.obj_hi[o])[axis];
+            float* d = slab + o * 12u + axis * 4u;
+            d[0] = lo; d[1] = hi; d[2] = lo; d[3] = 0.0f;
+        }
+    }
     __syncthreads();
+    sc.obj_slab = reinterpret_cast<const float*>(lds + ls.off_obj_slab / 4);
     sc.obj_lo = reinterpret_cast<const float4*>(lds + ls.off_obj_lo / 4);
     sc.obj_hi = reinterpret_cast<const float4*>(lds + ls.off_obj_hi / 4);
     sc.objects = reinterpret_cast<const DObject*>(lds + ls.off_objects / 4);

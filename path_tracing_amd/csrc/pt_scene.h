@@ -98,6 +98,9 @@ struct SceneView {
     uint32_t tie_lowest;  // 0: equal distances go to the later (object, triangle) as in the reference; 1: to the earlier
     uint32_t _pad1;
     // one mesh's BLAS staged in LDS by the kernel (PT_MODE_LIST_LB), null otherwise
+    // PT_MODE_LDS only: the padded world boxes staged in LDS as 12 floats per object, (lo, hi, lo, 0) per axis, so that a
+    // lane reads (near, far) of an axis as two consecutive words from an address chosen by the sign of its ray direction
+    const float* obj_slab;
     const BvhNode* lb_nodes;  // its nodes; a node reference r of that mesh is lb_nodes[r - lb_node_base]
     const DTri* lb_tris;      // its triangle records (null: they stay in global memory)
     uint32_t lb_mesh, lb_node_base;
@@ -126,7 +129,7 @@ struct SceneScalars {
     sc.textures = p_textures; sc.texture_data = p_texdata; sc.n_objects = ss.n_objects;                                 \
     sc.n_texture_data = ss.n_texture_data; sc.tlas_root = ss.tlas_root; sc.cull_boxes = ss.cull_boxes;                  \
     sc._pad0 = 0; sc.tie_lowest = ss.tie_lowest; sc._pad1 = 0;                                                       \
-    sc.lb_nodes = nullptr; sc.lb_tris = nullptr; sc.lb_mesh = 0xFFFFFFFFu; sc.lb_node_base = 0;
+    sc.obj_slab = nullptr; sc.lb_nodes = nullptr; sc.lb_tris = nullptr; sc.lb_mesh = 0xFFFFFFFFu; sc.lb_node_base = 0;
 
 // Per-frame constants.
 struct FrameParams {

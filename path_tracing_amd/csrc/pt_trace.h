@@ -136,6 +136,39 @@ PT_DEV bool slab_test(const SlabRay& s, float4 lo, float4 hi, float tmax, float&
     return tn <= tf;
 }
 
+// The same test against a box stored as (lo, hi, lo, 0) per axis (SceneView::obj_slab): the lane reads (near, far) of
+// an axis as two consecutive words starting at lo when its reciprocal direction is non-negative and at hi when it is
+// negative, so the six minimum/maximum operations that sort the plane distances of slab_test are not needed. For
+// inv >= 0 the fused products satisfy a <= b (lo <= hi, pad >= 0, rounding is monotonic), for inv < 0 the reverse:
+// the interval is the one slab_test computes, and so is every culling decision.
+struct SlabRaySel {
+    v3 inv, kn, kf;         // reciprocal direction; the constants of the near and of the far plane per axis
+    uint32_t ox, oy, oz;    // word offsets into an object's 12 floats
+};
+PT_DEV SlabRaySel make_slab_ray_sel(const SlabRay& s) {
+    SlabRaySel r;
+    const bool nx = (__float_as_uint(s.inv.x) >> 31) != 0u, ny = (__float_as_uint(s.inv.y) >> 31) != 0u, nz = (__float_as_uint(s.inv.z) >> 31) != 0u;
+    r.inv = s.inv;
+    r.kn = V3(nx ? s.kb.x : s.ka.x, ny ? s.kb.y : s.ka.y, nz ? s.kb.z : s.ka.z);
+    r.kf = V3(nx ? s.ka.x : s.kb.x, ny ? s.ka.y : s.kb.y, nz ? s.ka.z : s.kb.z);
+    r.ox = nx ? 1u : 0u;
+    r.oy = ny ? 5u : 4u;
+    r.oz = nz ? 9u : 8u;
+    return r;
+}
+PT_DEV bool slab_test_sel(const SlabRaySel& s, const float* box, float tmax, float& tnear) {
+    const float* px = box + s.ox;
+    const float* py = box + s.oy;
+    const float* pz = box + s.oz;
+    const float nx = pt_fma(px[0], s.inv.x, s.kn.x), fx = pt_fma(px[1], s.inv.x, s.kf.x);
+    const float ny = pt_fma(py[0], s.inv.y, s.kn.y), fy = pt_fma(py[1], s.inv.y, s.kf.y);
+    const float nz = pt_fma(pz[0], s.inv.z, s.kn.z), fz = pt_fma(pz[1], s.inv.z, s.kf.z);
+    const float tn = pt_max(pt_max(nx, ny), pt_max(nz, 0.0f));
+    const float tf = pt_min(pt_min(fx, fy), pt_min(fz, tmax));
+    tnear = tn;
+    return tn <= tf;
+}
+
 // Per-lane stack walk of a binary BVH in "while-while" form: every lane first descends through internal nodes
 // until it holds a leaf (or runs out of work), then the lanes that hold a leaf process it together. This keeps the
 // expensive leaf code (object or triangle test) running with as many lanes as possible. The descent is cut after
@@ -354,6 +387,8 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
     const SlabRay sr = world_slab_ray(ro, rd);
     const uint32_t n = sc.n_objects;
     const bool cull = sc.cull_boxes != 0;
+    SlabRaySel ss;
+    if (PERLANE) ss = make_slab_ray_sel(sr);
     for (uint32_t base = 0; base < n; base += 32) {
         const uint32_t m = (n - base < 32u) ? n - base : 32u;
         uint32_t mask = 0;
@@ -362,10 +397,10 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
         if (cull) {
             for (uint32_t k = 0; k < m; ++k) {
                 PT_COUNT(cnt, 8);
-                const float4 blo = sc.obj_lo[base + k], bhi = sc.obj_hi[base + k];
                 float tn;
                 if (STATS) cnt.box_tests++;
-                if (slab_test(sr, blo, bhi, best.t, tn)) {
+                if (PERLANE ? slab_test_sel(ss, sc.obj_slab + 12u * (base + k), best.t, tn)
+                            : slab_test(sr, sc.obj_lo[base + k], sc.obj_hi[base + k], best.t, tn)) {
                     mask |= 1u << k;
                     if (tn < near_t) { near_t = tn; near_k = k; }
                 }
@@ -384,7 +419,7 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
                 const uint32_t o = base + k;
                 mask &= ~(1u << k);
                 float tn;
-                if (!cull || slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn)) object_test<STATS, PERLANE, LB>(sc, o, ro, rd, best, stk, 0, cnt);
+                if (!cull || (PERLANE ? slab_test_sel(ss, sc.obj_slab + 12u * o, best.t, tn) : slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn))) object_test<STATS, PERLANE, LB>(sc, o, ro, rd, best, stk, 0, cnt);
             }
         }
     }
