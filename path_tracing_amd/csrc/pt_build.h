@@ -81,7 +81,7 @@ __global__ void k_prep_objects(const WObject* __restrict__ wobj, const uint32_t*
     d.mat = w->mat;
     d.mesh = w->mesh;
     d.tri_base = tri_base[o];
-    d._pad0 = 0;
+    d.tri_first = meshes[w->mesh].tri_first;
     d._pad1[0] = d._pad1[1] = d._pad1[2] = d._pad1[3] = 0;
     objects[o] = d;
 

@@ -741,6 +741,9 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             if (cnt.passes >= PT_WAVE_PRIO_PASSES) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
             PT_COUNT(cnt, 7);
+#ifdef PT_EXEC_COUNTS
+            unsigned long long tf = __builtin_amdgcn_s_memtime();
+#endif
             if (tracing) {
                 PT_COUNT(cnt, 12);
                 nrays++;
@@ -749,6 +752,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 h = finalize_hit(sc, rpos, rdir, b);
                 st = PT_ST_SHADE;
             }
+            PT_COUNT_CYCLES(cnt, 15, tf);   // list scenes: cycles of the hit records
         }
         if (STATS) {
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();

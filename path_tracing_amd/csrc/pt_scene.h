@@ -11,7 +11,7 @@ struct DObject {
     uint32_t mat;
     uint32_t mesh;
     uint32_t tri_base;   // flat triangle id of this object's triangle 0 (order of the reference's double loop)
-    uint32_t _pad0;
+    uint32_t tri_first;  // == meshes[mesh].tri_first, so that the hit record needs no trip through the mesh record
     uint32_t _pad1[4];
 };
 static_assert(sizeof(DObject) == 128, "DObject");

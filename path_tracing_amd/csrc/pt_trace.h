@@ -32,9 +32,12 @@ struct HitInfo {
 #define PT_COUNT(cnt, k) do { if ((uint32_t)(threadIdx.x & 63) == (uint32_t)__builtin_ctzll(__ballot(1))) (cnt).exec[k]++; } while (0)
 // the same, adding the number of lanes for which `cond` holds
 #define PT_COUNT_LANES(cnt, k, cond) do { const uint32_t n_ = (uint32_t)__popcll(__ballot(cond)); if ((uint32_t)(threadIdx.x & 63) == (uint32_t)__builtin_ctzll(__ballot(1))) (cnt).exec[k] += n_; } while (0)
+// wave cycles since `t0` (and restart the clock)
+#define PT_COUNT_CYCLES(cnt, k, t0) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((uint32_t)(threadIdx.x & 63) == (uint32_t)__builtin_ctzll(__ballot(1))) (cnt).exec[k] += (uint32_t)(now_ - (t0)); (t0) = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PT_COUNT(cnt, k) do { } while (0)
 #define PT_COUNT_LANES(cnt, k, cond) do { } while (0)
+#define PT_COUNT_CYCLES(cnt, k, t0) do { } while (0)
 #endif
 struct LaneCounters {
     uint32_t xforms, box_tests, tri_tests, shades, hits;
@@ -384,6 +387,9 @@ PT_DEV SlabRay world_slab_ray(v3 ro, v3 rd) {
 // With sc.cull_boxes == 0 (PT_ACCEL_BRUTE) every object is a candidate: the reference's exhaustive loop.
 template <bool STATS, bool PERLANE, bool LB = false>
 PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
+#ifdef PT_EXEC_COUNTS
+    unsigned long long tc = __builtin_amdgcn_s_memtime();
+#endif
     const SlabRay sr = world_slab_ray(ro, rd);
     const uint32_t n = sc.n_objects;
     const bool cull = sc.cull_boxes != 0;
@@ -409,6 +415,7 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
             mask = (m == 32u) ? 0xFFFFFFFFu : ((1u << m) - 1u);
         }
         if (!active) mask = 0;
+        PT_COUNT_CYCLES(cnt, 13, tc);   // list scenes: cycles of the box loop
         bool first = cull;
         while (__any(mask != 0)) {
             cnt.passes++;
@@ -422,6 +429,7 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
                 if (!cull || (PERLANE ? slab_test_sel(ss, sc.obj_slab + 12u * o, best.t, tn) : slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn))) object_test<STATS, PERLANE, LB>(sc, o, ro, rd, best, stk, 0, cnt);
             }
         }
+        PT_COUNT_CYCLES(cnt, 14, tc);   // list scenes: cycles of the candidate passes
     }
 }
 
@@ -463,8 +471,7 @@ PT_DEV HitInfo finalize_hit(const SceneView& sc, v3 ro, v3 rd, const Best& b) {
     Affine w2l = ob->w2l, l2w = ob->l2w;
     v3 lo = xform_point(w2l, ro);
     v3 ld = xform_dir(w2l, rd);
-    uint32_t tri_first = sc.meshes[ob->mesh].tri_first;
-    const DTriAttr* A = &sc.tri_attrs[tri_first + b.tri];
+    const DTriAttr* A = &sc.tri_attrs[ob->tri_first + b.tri];
     float4 a0 = A->q0, a1 = A->q1, a2 = A->q2, a3 = A->q3;
     float u = b.u, v = b.v;
     float w = 1.0f - u - v;

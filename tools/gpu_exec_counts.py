@@ -8,7 +8,8 @@ from path_tracing_amd import abi, scenes
 from tools.gpu_perf import SCENES
 NAMES = ["shade loop pass", "step 1 (any lane)", "add_emitted (hit)", "next_sample in step 1", "add_emitted (restart)", "scatter (brdf)",
          "next_sample after scatter", "trace executed", "world box test (wave)", "object pass", "triangle loop iteration", "exact gate", "finalize",
-         "TLAS: lanes in node visits", "TLAS: lanes in leaf calls", "global tri loop: lanes inside"]
+         "TLAS: lanes in node visits | list: cycles in the box loop", "TLAS: lanes in leaf calls | list: cycles in candidate passes",
+         "global tri loop: lanes inside | list: cycles in hit records"]
 # (TLAS scenes reuse three rows: "world box test" = node-visit iterations of the resumable walk, "object pass" = its leaf calls,
 #  "triangle loop iteration" = iterations of the global-memory triangle loop)
 for n in (sys.argv[1:] or ["boxes"]):
