@@ -44,6 +44,13 @@ from path_tracing_amd import abi, scenes  # noqa: E402
 WORK = {"xforms": (33 + 25, 96 + 24), "box_tests": (25, 32), "tri_tests": (53, 36), "hits": (73, 60), "shades": (200, 64)}
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 (256 CU x 128 lanes x 2 flop x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0
+# What one wave64 VALU instruction costs a SIMD that holds four waves (the occupancy k_paths runs at), measured with
+# tools/micro/valu_mix.hip on this part: v_fma_f32 3.85 cycles, min/max/compare/convert/select 4.2, add/mul/mov/
+# integer add 2.4, reciprocal and square root 8.2, packed f32 4.2-4.6. 3.9 is the mean over k_paths' mix. The
+# 157.3 TFLOP/s peak needs a packed fused multiply-add every 4.6 cycles; a stream of single FMAs tops out at 83.
+VALU_CYCLES_PER_INST = 3.9
+N_SIMD = 1024
+SHADER_GHZ = 2.4
 
 WORKLOADS = {
     "boxes": ("examples/boxes.rs scene, 1920x1080, 64 spp, 10 bounces", lambda: scenes.boxes(1920, 1080, 64, 10)),
@@ -241,10 +248,23 @@ def main():
         compulsory = scene_bytes + W * H * 32
         achieved_tflops = flops / (k_ms * 1e-3) / 1e12
         traffic = None
+        issue = None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
-                traffic = json.loads(tf.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+                prof = json.loads(tf.read_text()).get(args.workload, {})
+                traffic = prof.get("hbm_bytes_per_launch")
+                if prof.get("SQ_INSTS_VALU"):
+                    # instruction-issue view of the same kernel: VALU wave-instructions per launch (rocprofv3 PMC pass of
+                    # tools/profile.sh) x the measured issue cost, against the kernel's duration on all SIMDs
+                    n_inst = float(prof["SQ_INSTS_VALU"])
+                    issue_ms = n_inst / N_SIMD * VALU_CYCLES_PER_INST / (SHADER_GHZ * 1e9) * 1e3
+                    issue = {"valu_wave_insts_per_launch": int(n_inst), "cycles_per_inst": VALU_CYCLES_PER_INST,
+                             "issue_ms": round(issue_ms, 4), "frac_of_kernel_ms": round(issue_ms / k_ms, 4),
+                             "frac_of_ms_per_step": round(issue_ms / ms_per_step, 4),
+                             "lanes_active_per_inst": round(float(prof["SQ_THREAD_CYCLES_VALU"]) / (float(prof["SQ_ACTIVE_INST_VALU"]) * 64.0), 4)
+                             if prof.get("SQ_THREAD_CYCLES_VALU") and prof.get("SQ_ACTIVE_INST_VALU") else None,
+                             "profile": prof.get("tag")}
             except Exception:
                 traffic = None
         line = {
@@ -281,6 +301,7 @@ def main():
                          "on_chip_bytes_per_launch": int(abytes),
                          "hbm": {"compulsory_bytes_per_launch": int(compulsory), "achieved_GBs": round(compulsory / (k_ms * 1e-3) / 1e9, 2),
                                  "peak_GBs": PEAK_HBM_GBS, "frac": round(compulsory / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)},
+                         "valu_issue": issue,
                          "counts": work},
         }
         if world == 1 and not args.no_cpu_baseline:

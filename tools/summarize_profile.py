@@ -96,6 +96,9 @@ def main():
         tf = dst / "traffic.json"
         cur = json.loads(tf.read_text()) if tf.exists() else {}
         cur[args.workload] = {"hbm_bytes_per_launch": hbm["hbm_bytes_per_launch"], "tag": args.tag}
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"):
+            if c in counters:
+                cur[args.workload][c] = counters[c]
         tf.write_text(json.dumps(cur, indent=1) + "\n")
     (dst / f"{args.tag}_summary.json").write_text(json.dumps(out, indent=1) + "\n")
     print(json.dumps(out, indent=1))
