@@ -46,9 +46,11 @@ PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 (256 CU x 128 lanes x 2 flo
 PEAK_HBM_GBS = 8000.0
 # What one wave64 VALU instruction costs a SIMD that holds four waves (the occupancy k_paths runs at), measured with
 # tools/micro/valu_mix.hip on this part: v_fma_f32 3.85 cycles, min/max/compare/convert/select 4.2, add/mul/mov/
-# integer add 2.4, reciprocal and square root 8.2, packed f32 4.2-4.6. 3.9 is the mean over k_paths' mix. The
-# 157.3 TFLOP/s peak needs a packed fused multiply-add every 4.6 cycles; a stream of single FMAs tops out at 83.
-VALU_CYCLES_PER_INST = 3.9
+# integer add 2.4, reciprocal and square root 8.2, packed f32 4.2-4.6. 3.35 is the mean over k_paths' measured mix
+# (SQ_INSTS_VALU_* counters on boxes: 20 % FMA, 14 % MUL, 4 % ADD, 13 % INT32, 1 % transcendental, 46 % min/max/compare/
+# select/move/bit operations priced at 3.5). The 157.3 TFLOP/s peak needs a packed fused multiply-add every 4.6 cycles; a
+# stream of single FMAs tops out at 83.
+VALU_CYCLES_PER_INST = 3.35
 N_SIMD = 1024
 SHADER_GHZ = 2.4
 
