@@ -347,6 +347,7 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
 #define PT_ST_IDLE 0u
 #define PT_ST_SHADE 1u
 #define PT_ST_TRACE 2u
+#define PT_ST_RESTART 3u   // a new sample whose first hit, the cached primary hit, is shaded in the wave's next round
 #ifndef PT_WAVE_PRIO_PASSES
 #define PT_WAVE_PRIO_PASSES 2u  // object-test passes in a round from which a wave raises its issue priority
 #endif
@@ -624,8 +625,20 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             const v3 alb = V3(m->albedo[0], m->albedo[1], m->albedo[2]);
             return dot3(alb, alb) < PT_EPSILON;
         };
-        bool pending = st == PT_ST_SHADE;
-        while (__any(pending)) {
+        // One pass per round. A lane whose path ends AFTER scattering (throughput below the cutoff that could not be
+        // foreseen, or the bounce limit in the general case) has begun its next sample too late for this round's
+        // scatter step: it waits one round (PT_ST_RESTART, 3 in 1000 rounds on the example scenes) rather than
+        // making the whole wave loop here.
+        bool pending = st == PT_ST_SHADE || st == PT_ST_RESTART;
+        if (st == PT_ST_RESTART) {
+            h.obj = slot_u[(PT_SLOT_HIT + 0) * 64];
+            h.p = V3(slot[(PT_SLOT_HIT + 1) * 64], slot[(PT_SLOT_HIT + 2) * 64], slot[(PT_SLOT_HIT + 3) * 64]);
+            h.n = V3(slot[(PT_SLOT_HIT + 4) * 64], slot[(PT_SLOT_HIT + 5) * 64], slot[(PT_SLOT_HIT + 6) * 64]);
+            h.u = slot[(PT_SLOT_HIT + 7) * 64];
+            h.v = slot[(PT_SLOT_HIT + 8) * 64];
+            st = PT_ST_SHADE;
+        }
+        if (__any(pending)) {
             PT_COUNT(cnt, 0);
             // 1. (cheap) a path that ends on this hit, a miss or a black surface, restarts from the primary hit ...
             bool restarted = false;
@@ -689,9 +702,10 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 const float p = pt_max(ray_color.x, pt_max(ray_color.y, ray_color.z));
                 bounce++;
                 if (p < PT_EPSILON || bounce >= bounces) {
-                    // dark path or bounce limit: next sample; its primary hit is shaded in another pass of this loop
+                    // dark path or bounce limit: next sample; its primary hit is shaded in the next round
                     PT_COUNT(cnt, 6);
-                    pending = next_sample();
+                    if (next_sample()) st = PT_ST_RESTART;
+                    pending = false;
                 } else {
                     st = PT_ST_TRACE;
                     pending = false;
