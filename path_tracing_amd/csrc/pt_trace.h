@@ -392,11 +392,14 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
 #endif
     const SlabRay sr = world_slab_ray(ro, rd);
     const uint32_t n = sc.n_objects;
-    const bool cull = sc.cull_boxes != 0;
+    const bool cull = PERLANE || sc.cull_boxes != 0;
     SlabRaySel ss;
     if (PERLANE) ss = make_slab_ray_sel(sr);
-    for (uint32_t base = 0; base < n; base += 32) {
-        const uint32_t m = (n - base < 32u) ? n - base : 32u;
+    // (scenes staged in LDS have at most 32 objects: one group, and culling is always on)
+    const uint32_t n_groups = PERLANE ? (n ? 1u : 0u) : (n + 31u) / 32u;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t base = PERLANE ? 0u : g * 32u;
+        const uint32_t m = PERLANE ? n : ((n - base < 32u) ? n - base : 32u);
         uint32_t mask = 0;
         uint32_t near_k = 0;      // the candidate whose box the ray enters first is tested first: it usually holds the
         float near_t = PT_T_MAX;  // closest hit, and the others are then culled by distance
