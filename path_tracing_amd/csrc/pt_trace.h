@@ -299,25 +299,25 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
             if (n > PT_LOCAL_BOX_MIN_TRIS) {
                 float tn;
                 const SlabRay sr = make_slab_ray(lo, ld, pad);
-                if (!slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn))
+                if (!slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), best.t, tn))
                     return;
             }
             for (uint32_t i = 0; i < n; ++i) {
                 PT_COUNT(cnt, 10);
                 const DTri* T = &sc.tris[tri_first + i];
-                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
+                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, best, cnt);
             }
         } else {
             const SlabRay sr = make_slab_ray(lo, ld, pad);
-            bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, 0u, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
+            bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, 0u, root, sr, best.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
                 const DTri* T = &sc.tris[tri_first + tri];
-                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
+                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, best, cnt);
             });
         }
         if (changed) {
             PT_COUNT(cnt, 11);
             const float t_aabb = hit_box_exact(me->bmin, me->bmax, lo, ld);   // reference :77-80
-            if (!(t_aabb < PT_T_MIN)) best = cand;
+            if (t_aabb < PT_T_MIN) best = cand;   // the gate rejects the object: back to the closest hit before it (rare)
         }
         return;
     }
@@ -419,18 +419,20 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
         }
         if (!active) mask = 0;
         PT_COUNT_CYCLES(cnt, 13, tc);   // list scenes: cycles of the box loop
-        bool first = cull;
+        // Every lane that has candidates takes part in the first pass, with the candidate it enters first; that one
+        // needs no second look at its box (nothing has shortened the ray since the box loop).
+        bool first = cull;   // wave-uniform
         while (__any(mask != 0)) {
             cnt.passes++;
             PT_COUNT(cnt, 9);
             if (mask != 0) {
                 const uint32_t k = first ? near_k : (uint32_t)__builtin_ctz(mask);
-                first = false;
                 const uint32_t o = base + k;
                 mask &= ~(1u << k);
                 float tn;
-                if (!cull || (PERLANE ? slab_test_sel(ss, sc.obj_slab + 12u * o, best.t, tn) : slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn))) object_test<STATS, PERLANE, LB>(sc, o, ro, rd, best, stk, 0, cnt);
+                if (!cull || first || (PERLANE ? slab_test_sel(ss, sc.obj_slab + 12u * o, best.t, tn) : slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn))) object_test<STATS, PERLANE, LB>(sc, o, ro, rd, best, stk, 0, cnt);
             }
+            first = false;
         }
         PT_COUNT_CYCLES(cnt, 14, tc);   // list scenes: cycles of the candidate passes
     }
