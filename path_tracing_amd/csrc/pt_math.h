@@ -47,6 +47,19 @@ PT_DEV v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
 PT_DEV v3 madd3(v3 a, v3 b, float s) { return V3(pt_fma(b.x, s, a.x), pt_fma(b.y, s, a.y), pt_fma(b.z, s, a.z)); }
 PT_DEV float pt_div(float a, float b) { return a / b; }       // correctly rounded (hipcc default)
 PT_DEV float pt_sqrt(float a) { return __builtin_sqrtf(a); }  // correctly rounded (hipcc default)
+// Correctly rounded square root for arguments that are 0 or in [2^-96, 2^64): the hardware's 1-ulp v_sqrt_f32 and the
+// same final step the compiler's expansion of sqrtf takes (the two neighbouring values are tried with an exact fused
+// residual), without its rescaling of tiny arguments and its special-case pass for zero, infinity and NaN, which
+// those arguments never need (a zero argument comes through as zero: both neighbour tests fail). The arguments of
+// cosine_sample, r and 1 - r with r = fract(u32 / 3141.59...), are 0 or at least 2^-24. Seven instructions fewer.
+PT_DEV float pt_sqrt_in_range(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_down = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_down = pt_fma(-s_down, s, x), r_up = pt_fma(-s_up, s, x);
+    float r = (r_down <= 0.0f) ? s_down : s;
+    r = (r_up > 0.0f) ? s_up : r;
+    return r;
+}
 // 1/sqrt(d) by a fixed recipe of f32 operations (identical in the CPU restatement): integer seed, three Newton steps.
 // At most 1.92 ulp from the exact value for d in [2^-100, 2^100] (checked over every f32 in that range), inside the 2 ulp
 // WGSL allows inverseSqrt. No division, no square root instruction (both are quarter rate and need long fix-up

@@ -549,8 +549,8 @@ PT_DEV void brdf_sample(Rng& rng, v3 ray_dir, v3 N, float rough_in, const BrdfFr
     pcg3d(rng);
     float r0 = rand_component(rng.x), r1 = rand_component(rng.y);
     float phi = 2.0f * PT_PI * r0;
-    float sin_theta = pt_sqrt(r1);
-    float cos_theta = pt_sqrt(1.0f - r1);
+    float sin_theta = pt_sqrt_in_range(r1);          // r1 is 0 or >= 2^-24, 1 - r1 is in [2^-24, 1]
+    float cos_theta = pt_sqrt_in_range(1.0f - r1);
     float sn, cs;
     pt_sincos(phi, sn, cs);
     v3 c = V3(sin_theta * cs, sin_theta * sn, cos_theta);

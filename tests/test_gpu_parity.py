@@ -166,6 +166,18 @@ def test_unused_scatters_against_oracle(bounces):
         assert np.array_equal(got["image"].view(np.uint32), ref["image"].view(np.uint32)), "image not bit-identical"
 
 
+def test_in_range_sqrt_is_correctly_rounded():
+    """cosine_sample's square roots use a shorter sequence than the compiler's sqrtf; the checker compares the two on
+    the device for every f32 in [2^-96, 2^64) and for zero (tools/micro/sqrt_check.hip, built by build())."""
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "tools" / "micro" / "sqrt_check"
+    assert exe.exists(), "tools/micro/sqrt_check is not built (run __graft_entry__.build())"
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 differ" in r.stdout
+
+
 def test_query_random_rays_against_oracle():
     scene = scenes.instanced_boxes(n_objects=3000, width=8, height=8, samples=1, extent=10.0)
     g = np.random.Generator(np.random.PCG64(99))
