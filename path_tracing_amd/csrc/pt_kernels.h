@@ -158,7 +158,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
                                                  PathRec* __restrict__ recs, uint32_t* __restrict__ cost, uint32_t use_hint,
                                                  DCounters* __restrict__ counters) {
     PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ uint32_t s_mem[];  // [WAVES][stack_depth][64 lanes], then the staged scene (PT_MODE_LDS)
+    // (16-byte aligned: the workgroup's static LDS words come first, and the staged records are read 16 bytes at a time)
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];  // [WAVES][stack_depth][64 lanes], then the staged scene (PT_MODE_LDS)
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + WAVES * stack_depth * 64);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Which tile this wave takes. Whole frames with 16 waves: the workgroup covers a 4x4 group of tiles (32x32
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     PT_SCENE_VIEW_FROM_PARAMS()
     // [4 waves][stack_depth][64 lanes] stacks, [4 waves][lane_slots(MODE)][64 lanes], [4 waves][PT_SCHED_WORDS], staged scene
     constexpr uint32_t SLOTS = lane_slots(MODE);
-    extern __shared__ uint32_t s_mem[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     const uint32_t lds_fixed = 4 * (stack_depth + SLOTS) * 64 + 4 * PT_SCHED_WORDS;
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + lds_fixed);
     if (MODE == PT_MODE_LIST_LB) stage_blas_in_lds(sc, lb, s_mem + lds_fixed);
@@ -842,7 +843,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_depth, const DRay* __restrict__ rays,
                                                uint32_t n_rays, DHit* __restrict__ hits) {
     PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;
     stk.base = &s_stack[wave * stack_depth * 64 + lane];
