@@ -273,6 +273,62 @@ def test_boxes_1080p_repeated_frames_bit_identical(monkeypatch):
         assert np.array_equal(ctx.render(scene.frame(time=1.5)).view(np.uint32), img_t.view(np.uint32))
 
 
+def test_scene_glb_1080p_accel_invariance_and_oracle_crop():
+    """Benchmark resolution of the glb workload (fewer samples): exhaustive loop, object list + BLAS, and the repeated
+    frame that stages the BLAS in LDS all give the same bits; a crop over Suzanne against the CPU restatement."""
+    scene = scenes.scene_glb_textured(1920, 1080, 8, 10)
+    frame = scene.frame()
+    a = render_all(scene, frame, abi.PT_ACCEL_BRUTE)
+    b = render_all(scene, frame, abi.PT_ACCEL_BVH)
+    assert np.array_equal(a["image"].view(np.uint32), b["image"].view(np.uint32))
+    assert np.array_equal(a["primary_flat_id"], b["primary_flat_id"])
+    assert np.array_equal(a["primary_t"].view(np.uint32), b["primary_t"].view(np.uint32))
+    assert np.array_equal(a["ray_count"], b["ray_count"])
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        for _ in range(3):   # from the second frame on the path kernel runs with the previous frame's ray counts as hints
+            img = ctx.render(frame)
+            assert np.array_equal(img.view(np.uint32), a["image"].view(np.uint32))
+            assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), a["ray_count"])
+    assert np.isfinite(a["image"]).all() and np.all(a["image"][..., 3] == 1.0)
+    rect = (944, 520, 976, 544)
+    ref = oracle_render(scene, frame, rect=rect)
+    x0, y0, x1, y1 = rect
+    assert (ref["primary_object"] != abi.PT_U32_MAX).any()
+    assert np.array_equal(a["image"][y0:y1, x0:x1].view(np.uint32), ref["image"].view(np.uint32))
+    assert np.array_equal(a["primary_flat_id"][y0:y1, x0:x1], ref["primary_flat_id"])
+    assert np.array_equal(a["ray_count"][y0:y1, x0:x1], ref["ray_count"])
+
+
+def test_cornell_4k_accel_invariance_and_oracle_crop(monkeypatch):
+    """The 3840x2160 Cornell box (fewer samples than the 4096 of the benchmark configuration): the LDS-staged scene,
+    the global-memory object list and the exhaustive loop agree bit for bit; repeated frames too; a crop against the
+    CPU restatement; every path is accounted for."""
+    scene = scenes.cornell_4k(16)
+    frame = scene.frame()
+    a = render_all(scene, frame, abi.PT_ACCEL_AUTO)
+    b = render_all(scene, frame, abi.PT_ACCEL_BRUTE)
+    with monkeypatch.context() as mp:
+        mp.setenv("PT_AMD_NO_LDS_SCENE", "1")
+        c = render_all(scene, frame, abi.PT_ACCEL_AUTO)
+    for other in (b, c):
+        assert np.array_equal(a["image"].view(np.uint32), other["image"].view(np.uint32))
+        assert np.array_equal(a["primary_flat_id"], other["primary_flat_id"])
+        assert np.array_equal(a["ray_count"], other["ray_count"])
+    st = a["stats"]
+    assert st["paths"] == 3840 * 2160 * 16
+    assert st["rays_reference"] == int(a["ray_count"].astype(np.uint64).sum())
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        for _ in range(2):
+            assert np.array_equal(ctx.render(frame).view(np.uint32), a["image"].view(np.uint32))
+    rect = (1900, 1060, 1932, 1084)
+    ref = oracle_render(scene, frame, rect=rect)
+    x0, y0, x1, y1 = rect
+    assert np.array_equal(a["image"][y0:y1, x0:x1].view(np.uint32), ref["image"].view(np.uint32))
+    assert np.array_equal(a["ray_count"][y0:y1, x0:x1], ref["ray_count"])
+
+
 def test_million_triangles_tlas_vs_loop_and_oracle_crop():
     scene = scenes.instanced_boxes(83334, 1920, 1080, 1, 10)
     assert scene.n_triangles == 1000008
