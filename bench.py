@@ -11,7 +11,7 @@ with one RCCL all-reduce per step: N x 64 spp per step, per-GPU work fixed (weak
 `--multi-gpu tiles` instead splits the 8x8 tiles of ONE frame over the ranks (all-reduce = gather, image
 bit-identical to the one-GPU image, strong scaling).
 
-Frames are kept in flight (--frames-in-flight, default 2): that many contexts take the frames in turn on their own
+Frames are kept in flight (--frames-in-flight, default 3): that many contexts take the frames in turn on their own
 streams, so the start of a frame overlaps the tail of the previous one; results are those of one context.
 
 Prints ONE JSON line on rank 0.
@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (invalidates the headline config)")
     ap.add_argument("--cpu-spp", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="contexts that take the frames in turn (1: strictly one frame at a time)")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="contexts that take the frames in turn (1: strictly one frame at a time)")
     ap.add_argument("--multi-gpu", default="virtual_frames", choices=["virtual_frames", "tiles"],
                     help="N > 1: every GPU renders its own virtual frame (N x spp, weak scaling) or a share of the tiles of one frame (strong scaling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path with every rank on GPU 0")
