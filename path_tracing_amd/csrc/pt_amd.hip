@@ -105,6 +105,7 @@ struct pt_ctx {
     bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
     uint64_t last_n_paths = ~0ull; // entries of the path list of the last frame read back
     uint32_t walk_quota = 16;     // see PathParams::walk_quota
+    bool split_chunks = false;    // see PathParams::split_chunks: shorter single frames on scenes of long BVH walks, fewer frames per second when several are in flight
     bool lds_blas = true;         // object-list scenes: stage the biggest BLAS that fits in LDS (k_paths)
     uint32_t lds_per_cu = 160 * 1024;
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
@@ -212,6 +213,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (const char* e = std::getenv("PT_AMD_REFILL_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_min = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
+        if (std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = true;
         if (const char* e = std::getenv("PT_AMD_WALK_QUOTA")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->walk_quota = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_LDS_BLAS")) ctx->lds_blas = false;
         if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
@@ -862,6 +864,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         // short. Only with whole-chunk refill (a wave then owns one chunk at a time and can report it complete).
         pp.n_sweeps = 1;
         pp.walk_quota = ctx->walk_quota;
+        pp.split_chunks = ctx->split_chunks ? 1u : 0u;
         pp.sweep_end[0] = fp.samples;
         if (pp.refill_min == 64u && pp.chunk == 64u && fp.samples >= 16u && ctx->max_sweeps > 1u) {
             uint32_t n = 0, done = 0, left = fp.samples;

@@ -62,6 +62,7 @@ struct PathParams {
     uint32_t walk_quota;    // PT_MODE_TLAS: lanes that have to finish their walk before a round's trace step ends (1..64)
     uint32_t n_sweeps;      // the samples of a pixel are run in this many consecutive slices (1..PT_MAX_SWEEPS)
     uint32_t sweep_end[8];  // slice j runs samples [sweep_end[j-1], sweep_end[j]); sweep_end[n_sweeps-1] == samples
+    uint32_t split_chunks;  // 1: the most expensive chunks are handed out in parts (ChunkOrderInfo::n_split)
 };
 #define PT_MAX_SWEEPS 8
 
@@ -291,8 +292,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
 #ifndef PT_HEAVY_BIN
 #define PT_HEAVY_BIN 2u   // chunks from this bin up (0.25 extra rays per sample) are run in one piece, first
 #endif
+// The most expensive chunks of all (whole cost bins from the top, at most 1/PT_SPLIT_FRACTION of the chunks) are handed
+// out in PT_SPLIT_PARTS parts of 16 entries, one part to a wave: their pixels are the longest chains of dependent rays of
+// the frame, and a round of a wave that traces for 16 lanes is much shorter than one for 64 (it lasts as long as its
+// slowest lane). The lanes left idle are affordable: those chains are what the rest of the chip ends up waiting for.
+#ifndef PT_SPLIT_PARTS
+#define PT_SPLIT_PARTS 4u
+#endif
+#ifndef PT_SPLIT_FRACTION
+#define PT_SPLIT_FRACTION 32u
+#endif
 struct ChunkOrderInfo {
-    uint32_t n_chunks, n_heavy;
+    uint32_t n_chunks, n_heavy, n_split, _pad;
 };
 __global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__ cost, const DCounters* __restrict__ counters,
                                                     uint32_t samples, uint32_t* __restrict__ chunk_bin) {
@@ -319,14 +330,20 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
     for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024u) atomicAdd(&cnt[chunk_bin[c]], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t run = 0, heavy = 0;
+        uint32_t run = 0, heavy = 0, split = 0;
+        bool top = true;
         for (int b = (int)PT_COST_BINS - 1; b >= 0; --b) {   // most expensive bin first
             start[b] = run;
             run += cnt[b];
-            if ((uint32_t)b >= PT_HEAVY_BIN) heavy = run;
+            if ((uint32_t)b >= PT_HEAVY_BIN) {
+                heavy = run;
+                if (top && run <= n_chunks / PT_SPLIT_FRACTION) split = run; else if (cnt[b]) top = false;
+            }
         }
         info->n_chunks = n_chunks;
         info->n_heavy = heavy;
+        info->n_split = split;
+        info->_pad = 0;
     }
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024u) order[atomicAdd(&start[chunk_bin[c]], 1u)] = c;
@@ -405,6 +422,8 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     // (read once: the line that holds n_paths also holds the queue head, which every wave keeps hitting with atomics)
     const uint32_t total = counters->n_paths;  // written by k_primary, which ran before on the same stream
     const uint32_t n_heavy = (order_info && pp.n_sweeps > 1u) ? order_info->n_heavy : 0u;
+    // (not for scenes staged in LDS: their rounds are bound by instruction issue and cost the same for 16 lanes as for 64)
+    const uint32_t n_split = (MODE != PT_MODE_LDS && order_info && pp.n_sweeps > 1u && pp.split_chunks) ? order_info->n_split : 0u;   // <= n_heavy
 
     LaneCounters cnt = {};
     uint32_t lane_rays = 0;
@@ -444,7 +463,8 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                 // others with their first sweep; then sweep after sweep over the others.
                 const uint32_t n_chunks_total = (total + pp.chunk - 1u) / pp.chunk;
                 const uint32_t n_light = n_chunks_total - n_heavy;
-                const uint32_t n_items = n_chunks_total + (pp.n_sweeps - 1u) * n_light;
+                const uint32_t n_items = n_chunks_total + (pp.n_sweeps - 1u) * n_light + (PT_SPLIT_PARTS - 1u) * n_split;
+                bool solo = false;   // the item just taken is a part of a split chunk: this wave takes nothing else with it
                 uint32_t chunk_next = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_NEXT]);
                 uint32_t chunk_end = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_END]);
                 uint32_t report = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_REPORT]);
@@ -471,9 +491,16 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                             }
                             item = q;
                         }
-                        uint32_t j = 0, cpos = item;   // sweep, position in the chunk order
-                        if (item >= n_chunks_total) {
-                            const uint32_t r = item - n_chunks_total;
+                        // the queue starts with the parts of the split chunks, then goes on as described above
+                        uint32_t j = 0, cpos = item, part = PT_NONE;   // sweep, position in the chunk order
+                        if (item < PT_SPLIT_PARTS * n_split) {
+                            cpos = item / PT_SPLIT_PARTS;
+                            part = item - cpos * PT_SPLIT_PARTS;
+                        } else {
+                            cpos = item - (PT_SPLIT_PARTS - 1u) * n_split;
+                        }
+                        if (cpos >= n_chunks_total) {
+                            const uint32_t r = cpos - n_chunks_total;
                             j = 1u + r / n_light;
                             cpos = n_heavy + (r - (j - 1u) * n_light);
                         }
@@ -498,6 +525,12 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                         sw_len = (sw_end - sw_begin) | (sw_end >= pp.samples ? 0x80000000u : 0u);
                         chunk_next = c * pp.chunk;
                         chunk_end = (total - chunk_next < pp.chunk) ? total : chunk_next + pp.chunk;
+                        if (part != PT_NONE) {
+                            const uint32_t len = pp.chunk / PT_SPLIT_PARTS;
+                            chunk_next = min(chunk_next + part * len, chunk_end);
+                            chunk_end = min(chunk_next + len, chunk_end);
+                            solo = true;
+                        }
                         if (pp.n_sweeps > 1u && cpos >= n_heavy) report = c;
                         if (STATS) {
                             if (n_chunks == 0) first_entry = chunk_next;
@@ -562,6 +595,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
                     chunk_next += take;
                     m = __ballot(need);
                     if (report != PT_NONE && chunk_next == chunk_end) break;  // sweeps: one chunk per wave at a time
+                    if (solo && take != 0u) break;
                 }
                 if (lane == 0) {
                     sched[PT_SCHED_NEXT] = chunk_next; sched[PT_SCHED_END] = chunk_end;

@@ -273,7 +273,7 @@ def test_boxes_1080p_repeated_frames_bit_identical(monkeypatch):
         assert np.array_equal(ctx.render(scene.frame(time=1.5)).view(np.uint32), img_t.view(np.uint32))
 
 
-def test_scene_glb_1080p_accel_invariance_and_oracle_crop():
+def test_scene_glb_1080p_accel_invariance_and_oracle_crop(monkeypatch):
     """Benchmark resolution of the glb workload (fewer samples): exhaustive loop, object list + BLAS, and the repeated
     frame that stages the BLAS in LDS all give the same bits; a crop over Suzanne against the CPU restatement."""
     scene = scenes.scene_glb_textured(1920, 1080, 8, 10)
@@ -290,6 +290,13 @@ def test_scene_glb_1080p_accel_invariance_and_oracle_crop():
             img = ctx.render(frame)
             assert np.array_equal(img.view(np.uint32), a["image"].view(np.uint32))
             assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), a["ray_count"])
+    with monkeypatch.context() as mp:   # the most expensive chunks handed out in parts of 16 entries
+        mp.setenv("PT_AMD_SPLIT_CHUNKS", "1")
+        with abi.Context() as ctx:
+            ctx.upload_scene(scene)
+            for _ in range(3):
+                assert np.array_equal(ctx.render(frame).view(np.uint32), a["image"].view(np.uint32))
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), a["ray_count"])
     assert np.isfinite(a["image"]).all() and np.all(a["image"][..., 3] == 1.0)
     rect = (944, 520, 976, 544)
     ref = oracle_render(scene, frame, rect=rect)
@@ -374,7 +381,8 @@ def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
 
     run(3)   # (the glb scene: from the second frame on its big mesh's BLAS is staged in LDS)
     for env in ({"PT_AMD_SWEEPS": "1"}, {"PT_AMD_SWEEPS": "8"}, {"PT_AMD_NO_COST_HINTS": "1"}, {"PT_AMD_REFILL_MIN": "1"},
-                {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}, {"PT_AMD_NO_LDS_BLAS": "1"}, {"PT_AMD_WALK_QUOTA": "1"}, {"PT_AMD_WALK_QUOTA": "64"}):
+                {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}, {"PT_AMD_NO_LDS_BLAS": "1"}, {"PT_AMD_WALK_QUOTA": "1"}, {"PT_AMD_WALK_QUOTA": "64"},
+                {"PT_AMD_SPLIT_CHUNKS": "1"}, {"PT_AMD_SPLIT_CHUNKS": "1", "PT_AMD_NO_LDS_SCENE": "1"}):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
