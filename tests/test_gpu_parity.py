@@ -178,6 +178,27 @@ def test_in_range_sqrt_is_correctly_rounded():
     assert " 0 differ" in r.stdout
 
 
+def test_axis_parallel_rays_in_staged_scene_against_oracle():
+    """Rays with zero direction components through the LDS-staged scene's box tests (which pick the near and far plane
+    of an axis by the sign of the reciprocal direction): a camera on the z axis with an odd image size sends its centre
+    row, column and pixel along the axes, and mirrors facing the axes send them straight back."""
+    b = scenes.SceneBuilder()
+    cube = b.add_mesh(*scenes.cube_mesh(1.0))
+    plane = b.add_mesh(*scenes.plane_mesh((0, 1, 0), 4.0))
+    mirror = b.add_material(albedo=(0.9, 0.9, 0.9), roughness=0.0)
+    b.add_object(cube, mirror, scenes.translation(0, 0, 0))
+    b.add_object(cube, b.add_material(albedo=(0.8, 0.3, 0.2), roughness=0.0), scenes.translation(0, 0, 9))    # behind the camera
+    b.add_object(cube, b.add_material(albedo=(0.2, 0.8, 0.3), roughness=1.0), scenes.translation(2.0, 0, 0))
+    b.add_object(cube, b.add_material(albedo=(0, 0, 0), emissive=(2, 2, 2)), scenes.translation(-2.0, 0, 0))
+    b.add_object(plane, b.add_material(albedo=(0.5, 0.5, 0.5), roughness=0.0), scenes.translation(0, -0.5, 0))
+    scene = b.build("axes", scenes.Camera((0, 0, 5), (0, 0, 0)), sky_color=(0.2, 0.3, 0.5), width=33, height=33, samples=6, bounces=8)
+    frame = scene.frame()
+    ref = oracle_render(scene, frame)
+    for accel in ACCELS:
+        got = render_all(scene, frame, accel)
+        assert_same(got, ref["image"], ref["primary_object"], ref["primary_flat_id"], ref["primary_t"].view(np.uint32), ref["ray_count"])
+
+
 def test_query_random_rays_against_oracle():
     scene = scenes.instanced_boxes(n_objects=3000, width=8, height=8, samples=1, extent=10.0)
     g = np.random.Generator(np.random.PCG64(99))
