@@ -184,7 +184,11 @@ const char* pt_last_error(const pt_ctx* ctx);
 
 /* Replaces the three `write_buffer` calls of prepare_meshes
  * (reference src/extract.rs:131-144). Validates ranges, builds the per-mesh
- * triangle records and BLAS on the device. Zero counts are legal. */
+ * triangle records and BLAS on the device. Zero counts are legal.
+ * aabb_min/aabb_max of a mesh must enclose every vertex its triangles use, as
+ * the boxes the reference computes do (src/extract.rs:77-93): the library culls
+ * by distance with them, the reference only gates on them. A mesh whose box
+ * does not enclose its triangles is rejected with PT_ERR_INVALID_SCENE. */
 int pt_upload_meshes(pt_ctx* ctx,
                      const PtMesh* meshes, uint32_t n_meshes,
                      const uint32_t* indices, uint32_t n_indices,
@@ -200,6 +204,9 @@ int pt_upload_materials(pt_ctx* ctx,
 /* Replaces the per-frame `objects.write_buffer` of extract_visible
  * (reference src/extract.rs:337-342); rebuilds the TLAS, or, when the number of
  * objects is unchanged, refits its boxes (the image does not depend on which).
+ * An array identical to the one already uploaded returns at once and leaves
+ * frames in flight, the radiance accumulation and the schedule hints alone; any
+ * other upload starts a new accumulation (as PT_FRAME_RESET does).
  * The reference's `emissives` buffer is bound but never read by the shader and
  * is not taken. */
 int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects);

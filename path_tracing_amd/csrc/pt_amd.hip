@@ -93,6 +93,7 @@ struct pt_ctx {
     uint32_t obj_max_mesh = 0, obj_max_mat = 0;
     uint32_t max_blas_depth = 0, tlas_depth = 0, tlas_root = PT_NONE;
     bool have_meshes = false, have_materials = false, have_objects = false;
+    bool objects_built = false;   // the instance data on the device was derived from h_objects and the current meshes
     bool use_tlas = false;
     std::vector<PtObject> h_objects;  // kept so that a mesh re-upload can rebuild the instance data
 
@@ -250,6 +251,9 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
 int pt_destroy(pt_ctx* ctx) {
     if (!ctx) return PT_OK;
     (void)hipSetDevice(ctx->device);
+    // frames may still be running on a caller's stream: wait for them before any buffer they use is released
+    for (FrameSlot& sl : ctx->slot)
+        if (sl.ev1 && sl.pending) (void)hipEventSynchronize(sl.ev1);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->w_meshes, &ctx->w_indices, &ctx->w_vertices, &ctx->w_objects, &ctx->d_meshes, &ctx->d_tris,
                       &ctx->d_attrs, &ctx->d_tri_lo, &ctx->d_tri_hi, &ctx->d_blas_nodes, &ctx->d_objects, &ctx->d_obj_lo,
@@ -261,7 +265,6 @@ int pt_destroy(pt_ctx* ctx) {
     for (DevBuf* b : bufs) b->release();
     for (void* p : ctx->host_allocs) (void)hipHostFree(p);
     for (FrameSlot& sl : ctx->slot) {
-        if (sl.ev1 && sl.pending) (void)hipEventSynchronize(sl.ev1);
         sl.counters.release();
         sl.counters_k1.release();
         if (sl.ev0) (void)hipEventDestroy(sl.ev0);
@@ -296,9 +299,16 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
             const PtMesh& me = meshes[m];
             if ((uint64_t)me.ihead + 3ull * me.tri_count > n_indices)
                 return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_meshes: mesh " + std::to_string(m) + " index range exceeds indices[]");
-            for (uint32_t i = 0; i < 3u * me.tri_count; ++i)
+            for (uint32_t i = 0; i < 3u * me.tri_count; ++i) {
                 if ((uint64_t)me.vhead + indices[me.ihead + i] >= n_vertices)
                     return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_meshes: mesh " + std::to_string(m) + " references a vertex past vertices[]");
+                // The mesh box is used to cull by distance (the reference only gates on it), which is only equivalent
+                // when it encloses every triangle, as the boxes src/extract.rs:77-93 computes do.
+                const float* pos = vertices[me.vhead + indices[me.ihead + i]].position;
+                for (int k = 0; k < 3; ++k)
+                    if (!(pos[k] >= me.aabb_min[k] && pos[k] <= me.aabb_max[k]))
+                        return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_meshes: mesh " + std::to_string(m) + " has a vertex outside its aabb_min/aabb_max");
+            }
             total_tris += me.tri_count;
         }
         if (total_tris >= 0x7FFFFFFFull) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_upload_meshes: too many triangles");
@@ -442,7 +452,6 @@ int pt_upload_materials(pt_ctx* ctx, const PtMaterial* materials, uint32_t n_mat
 int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
-        { int rc_wait = finish_timing(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
         if (n_objects && !objects) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_objects: null array with non-zero count");
         if (n_objects >= 0x7FFFFFFFu) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_upload_objects: too many objects");
         for (uint32_t o = 0; o < n_objects; ++o) {
@@ -450,8 +459,15 @@ int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects) 
                 if (!std::isfinite(objects[o].local_to_world[k]) || !std::isfinite(objects[o].world_to_local[k]))
                     return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_objects: object " + std::to_string(o) + " has a non-finite matrix");
         }
+        // The reference rewrites the object buffer every frame (src/extract.rs:297-346), mostly with the same bytes:
+        // then the instance data, the TLAS, the cost hints and the frames in flight all stay as they are.
+        if (ctx->have_objects && ctx->objects_built && ctx->h_objects.size() == n_objects &&
+            (n_objects == 0 || std::memcmp(ctx->h_objects.data(), objects, sizeof(PtObject) * (size_t)n_objects) == 0))
+            return PT_OK;
+        { int rc_wait = finish_timing(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
         ctx->h_objects.assign(objects, objects + n_objects);
         ctx->have_objects = true;
+        ctx->objects_built = false;
         ctx->scene_version++;
         ctx->acc_frames = 0;
         if (!ctx->have_meshes) {  // instance data is derived once the mesh table exists
@@ -502,7 +518,8 @@ int rebuild_objects(pt_ctx* ctx) {
     ctx->tlas_depth = 0;
     ctx->use_tlas = false;
     ctx->stats.build_ms = 0.0;
-    if (n == 0) return PT_OK;
+    ctx->objects_built = false;
+    if (n == 0) { ctx->objects_built = true; return PT_OK; }
 
     PT_HIP(ctx, ctx->w_objects.ensure(sizeof(PtObject) * (size_t)n));
     PT_HIP(ctx, ctx->d_objects.ensure(sizeof(DObject) * (size_t)n));
@@ -564,6 +581,7 @@ int rebuild_objects(pt_ctx* ctx) {
     if (hipEventElapsedTime(&ms, ctx->evb0, ctx->evb1) == hipSuccess) ctx->stats.build_ms = ms;
     ctx->tlas_depth = depth;
     ctx->tlas_refitted = refitted;
+    ctx->objects_built = true;
     return PT_OK;
 }
 
@@ -700,8 +718,9 @@ int scene_mode(const pt_ctx* ctx, LdsScene* ls) {
     return PT_MODE_LDS;
 }
 
-// Enqueue one frame on `s`, image to device memory `out`.
-int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
+// Enqueue one frame on `s`, image to device memory `out`; with `out16` the image is also packed to binary16 there,
+// inside the span the frame's completion event covers.
+int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uint2* out16 = nullptr) {
     int rc = check_ready(ctx, "pt_render");
     if (rc != PT_OK) return rc;
     if (f->width == 0 || f->height == 0) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: zero-sized frame");
@@ -835,7 +854,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
         // Only when the last finished frame of this view listed so few pixels that one workgroup per compute unit
         // takes them all anyway (a frame full of such pixels is better served by more workgroups).
         if (mode == PT_MODE_LIST && ctx->lds_blas && use_hint && ctx->last_n_paths <= (uint64_t)ctx->n_cus * 256u * 4u) {
-            const size_t budget = (size_t)ctx->lds_per_cu - 1024 - lds;
+            const size_t budget = (size_t)ctx->lds_per_cu > lds + 1024 ? (size_t)ctx->lds_per_cu - 1024 - lds : 0;
             uint32_t best = PT_NONE;
             for (uint32_t m = 0; m < ctx->n_meshes; ++m) {
                 if (ctx->h_blas_nodes_base[m] == PT_NONE || ctx->h_meshes[m].tri_count < 2) continue;
@@ -927,7 +946,8 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
     sl.primary_traced = (fp.bounces > 0 && fp.samples > 0) ? local_pixels : 0;  // one primary ray per pixel (k_primary)
 
     if (f->flags & (PT_FRAME_ACCUMULATE | PT_FRAME_RESET)) {
-        if ((f->flags & PT_FRAME_RESET) || ctx->acc_w != f->width || ctx->acc_h != f->height) {
+        // (acc_frames == 0: nothing accumulated yet, or the scene changed since: the old sum belongs to another scene)
+        if ((f->flags & PT_FRAME_RESET) || ctx->acc_w != f->width || ctx->acc_h != f->height || ctx->acc_frames == 0) {
             PT_HIP(ctx, ctx->d_acc.ensure(16 * n_pix));
             PT_HIP(ctx, hipMemsetAsync(ctx->d_acc.p, 0, 16 * n_pix, s));
             ctx->acc_w = f->width;
@@ -940,6 +960,10 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s) {
                                                                       (uint32_t)n_pix, (float)ctx->acc_frames);
             PT_HIP(ctx, hipGetLastError());
         }
+    }
+    if (out16) {
+        k_pack_f16<<<div_up((uint32_t)n_pix, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(out), out16, (uint32_t)n_pix);
+        PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(sl.ev1, s));
     sl.pending = true;
@@ -961,10 +985,8 @@ int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device, v
         if (frame->flags & PT_FRAME_OUTPUT_F16) {
             const size_t n_pix = (size_t)frame->width * frame->height;
             PT_HIP(ctx, ctx->d_out.ensure(16 * n_pix));
-            int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), s);
+            int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), s, reinterpret_cast<uint2*>(out_rgba_device));
             if (rc != PT_OK) return rc;
-            k_pack_f16<<<div_up((uint32_t)n_pix, 256), 256, 0, s>>>(ctx->d_out.as<float4>(), reinterpret_cast<uint2*>(out_rgba_device), (uint32_t)n_pix);
-            PT_HIP(ctx, hipGetLastError());
         } else {
             int rc = render_enqueue(ctx, frame, reinterpret_cast<float*>(out_rgba_device), s);
             if (rc != PT_OK) return rc;
@@ -985,15 +1007,10 @@ int pt_render(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_host) {
         const bool f16 = (frame->flags & PT_FRAME_OUTPUT_F16) != 0;
         const size_t out_bytes = (f16 ? 8 : 16) * n_pix;
         PT_HIP(ctx, ctx->d_out.ensure(16 * n_pix));
-        int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), ctx->stream);
+        if (f16) PT_HIP(ctx, ctx->d_out16.ensure(8 * n_pix));
+        int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), ctx->stream, f16 ? ctx->d_out16.as<uint2>() : nullptr);
         if (rc != PT_OK) return rc;
-        const void* src = ctx->d_out.p;
-        if (f16 && n_pix) {
-            PT_HIP(ctx, ctx->d_out16.ensure(8 * n_pix));
-            k_pack_f16<<<div_up((uint32_t)n_pix, 256), 256, 0, ctx->stream>>>(ctx->d_out.as<float4>(), ctx->d_out16.as<uint2>(), (uint32_t)n_pix);
-            PT_HIP(ctx, hipGetLastError());
-            src = ctx->d_out16.p;
-        }
+        const void* src = f16 ? ctx->d_out16.p : ctx->d_out.p;
         PT_HIP(ctx, hipMemcpyAsync(out_rgba_host, src, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return PT_OK;
@@ -1043,9 +1060,14 @@ int pt_query(pt_ctx* ctx, const PtRay* rays_host, uint32_t n_rays, PtHit* hits_h
         PT_HIP(ctx, hipMemcpyAsync(ctx->d_rays.p, rays_host, sizeof(PtRay) * (size_t)n_rays, hipMemcpyHostToDevice, s));
         SceneView sv = make_view(ctx);
         const uint32_t depth = stack_depth_needed(ctx);
-        const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t);
-        if (ctx->use_tlas) k_query<PT_MODE_TLAS><<<div_up(n_rays, 256), 256, lds, s>>>(PT_SCENE_ARGS(sv), depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
-        else k_query<PT_MODE_LIST><<<div_up(n_rays, 256), 256, lds, s>>>(PT_SCENE_ARGS(sv), depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        // the same organisation of the scene as the frame kernels use (small scenes: every record staged in LDS)
+        LdsScene ls;
+        const int mode = scene_mode(ctx, &ls);
+        const size_t lds = (size_t)4 * depth * 64 * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
+        const uint32_t grid = div_up(n_rays, 256);
+        if (mode == PT_MODE_TLAS) k_query<PT_MODE_TLAS><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        else if (mode == PT_MODE_LDS) k_query<PT_MODE_LDS><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
+        else k_query<PT_MODE_LIST><<<grid, 256, lds, s>>>(PT_SCENE_ARGS(sv), ls, depth, ctx->d_rays.as<DRay>(), n_rays, ctx->d_hits.as<DHit>());
         PT_HIP(ctx, hipGetLastError());
         PT_HIP(ctx, hipMemcpyAsync(hits_host, ctx->d_hits.p, sizeof(PtHit) * (size_t)n_rays, hipMemcpyDeviceToHost, s));
         PT_HIP(ctx, hipStreamSynchronize(s));

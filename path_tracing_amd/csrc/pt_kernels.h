@@ -874,10 +874,11 @@ struct DHit {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, uint32_t stack_depth, const DRay* __restrict__ rays,
+__global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, LdsScene ls, uint32_t stack_depth, const DRay* __restrict__ rays,
                                                uint32_t n_rays, DHit* __restrict__ hits) {
     PT_SCENE_VIEW_FROM_PARAMS()
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stack[];  // [4 waves][stack_depth][64 lanes], then the staged scene (PT_MODE_LDS)
+    if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_stack + 4 * stack_depth * 64);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;
     stk.base = &s_stack[wave * stack_depth * 64 + lane];

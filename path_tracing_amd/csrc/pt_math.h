@@ -12,7 +12,8 @@
 //   cross(a,b) = ( fma(a.y,b.z,-(a.z*b.y)), fma(a.z,b.x,-(a.x*b.z)), fma(a.x,b.y,-(a.y*b.x)) )
 //   M*(v,0)    : r_i = fma(M[2][i],v.z, fma(M[1][i],v.y, M[0][i]*v.x)); M*(v,1) adds M[3][i] last
 //   a + b*s    = fma(b,s,a);  mix(a,b,t) = fma(b,t, a*(1-t));  reflect(I,N) = fma(-(2*dot(N,I)), N, I)
-//   normalize(v) = v * (1 / sqrt(dot(v,v)));  pow(x,5) = ((x*x)*(x*x))*x
+//   normalize(v) = v * inverseSqrt(dot(v,v)), inverseSqrt by the fixed recipe of pt_rsqrt (integer seed, three Newton
+//   steps; within the 2 ulp WGSL allows inverseSqrt);  pow(x,5) = ((x*x)*(x*x))*x
 //   sin/cos: Cody-Waite reduction by pi/2 and fixed polynomials (pt_sincos).
 #pragma once
 

@@ -15,6 +15,8 @@ from path_tracing_amd.abi import HIT_DT, RAY_DT, PtFrame
 ROOT = Path(__file__).resolve().parent.parent
 ORACLE_DIR = ROOT / "oracle"
 ORACLE_SO = ORACLE_DIR / "libpt_oracle.so"
+# the same restatement with normalize() as v * (1 / sqrt(dot(v, v))), correctly rounded (-DPTO_IEEE_NORMALIZE)
+ORACLE_IEEE_SO = ORACLE_DIR / "libpt_oracle_ieee.so"
 
 
 class PtoScene(C.Structure):
@@ -33,19 +35,31 @@ class PtoAux(C.Structure):
 
 
 _lib = None
+_lib_ieee = None
 
 
 def build_oracle():
-    subprocess.run(["make", "-C", str(ORACLE_DIR), "libpt_oracle.so"], check=True, capture_output=True)
+    subprocess.run(["make", "-C", str(ORACLE_DIR), "all"], check=True, capture_output=True)
 
 
-def load_oracle():
-    global _lib
+def load_oracle(variant="recipe"):
+    """variant "recipe": the evaluation the kernels implement; "ieee": normalize() with sqrt and division."""
+    global _lib, _lib_ieee
+    if variant == "ieee":
+        if _lib_ieee is None:
+            if not ORACLE_IEEE_SO.exists():
+                build_oracle()
+            _lib_ieee = _declare(C.CDLL(str(ORACLE_IEEE_SO)))
+        return _lib_ieee
     if _lib is not None:
         return _lib
     if not ORACLE_SO.exists():
         build_oracle()
-    lib = C.CDLL(str(ORACLE_SO))
+    _lib = _declare(C.CDLL(str(ORACLE_SO)))
+    return _lib
+
+
+def _declare(lib):
     lib.pto_render.argtypes = [C.POINTER(PtoScene), C.POINTER(PtFrame), C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_uint32, C.c_void_p, C.POINTER(PtoAux), C.c_int]
     lib.pto_render.restype = C.c_int
@@ -59,7 +73,6 @@ def load_oracle():
     lib.pto_rsqrt.argtypes = [C.c_float]
     lib.pto_rsqrt.restype = C.c_float
     lib.pto_num_threads.restype = C.c_int
-    _lib = lib
     return lib
 
 
@@ -78,9 +91,9 @@ class OracleScene:
                           _p(t), t.size, _p(td), td.size)
 
 
-def oracle_render(scene, frame: PtFrame, rect=None, threads=0):
+def oracle_render(scene, frame: PtFrame, rect=None, threads=0, variant="recipe"):
     """Returns dict(image (h,w,4) f32, primary_object, primary_flat_id, primary_t, ray_count)."""
-    lib = load_oracle()
+    lib = load_oracle(variant)
     os_ = OracleScene(scene)
     x0, y0, x1, y1 = rect if rect is not None else (0, 0, frame.width, frame.height)
     h, w = y1 - y0, x1 - x0
