@@ -111,7 +111,8 @@ def test_distance_to_a_second_legal_evaluation(name, kw, bound, record_property)
     got = render_all(scene, frame)
     assert np.array_equal(got["primary_object"], ref["primary_object"])
     assert np.array_equal(got["primary_flat_id"], ref["primary_flat_id"])
-    assert np.array_equal(got["primary_t"].view(np.uint32), ref["primary_t"].view(np.uint32))
+    # (the camera ray's direction is itself a normalize(): the two evaluations differ in its last bit, and so may t)
+    assert np.allclose(got["primary_t"], ref["primary_t"], rtol=1e-6, atol=0.0)
     d = rrmse(got["image"], ref["image"])
     same = got["ray_count"] == ref["ray_count"]
     record_property("rrmse_vs_ieee_normalize", d)
