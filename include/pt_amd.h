@@ -226,6 +226,24 @@ int pt_render(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_host);
 int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
                      void* hip_stream);
 
+/* The same frame as pt_render_device without any device-memory allocation, for
+ * callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc. No counterpart in the reference.
+ * Everything the kernels need besides the scene, the image and the context (path
+ * list, parked pixel state, aux planes, work counters) lives in one fixed array
+ * per GPU that is part of the library's code object, sized for frames of at most
+ * PT_NOALLOC_MAX_PIXELS pixels, width and height each rounded up to a multiple
+ * of 8 (about 29 MiB per GPU, held until the process ends). Larger frames and
+ * frames with flags are refused with PT_ERR_UNSUPPORTED. The scene must have
+ * been uploaded before (uploads allocate). The image is bit-identical to
+ * pt_render_device's. The frame leaves no record in the context: pt_get_stats
+ * and pt_read_aux do not describe it. All calls on one GPU, from any context,
+ * share the array: calls that overlap in time on one GPU race; calls on one
+ * stream, or otherwise ordered, are safe. */
+#define PT_NOALLOC_MAX_PIXELS (1u << 18)   /* e.g. 512 x 512 */
+int pt_render_device_noalloc(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
+                             void* hip_stream);
+
 /* Page-locked host memory owned by the context, for the image pt_render returns
  * (and for the arrays handed to pt_upload_*): copies to and from it run at the
  * PCIe rate, about three times the rate of pageable memory on the test machine.

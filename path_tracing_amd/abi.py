@@ -35,6 +35,8 @@ PT_FRAME_OUTPUT_F16 = 0x4
 PT_ACCEL_AUTO, PT_ACCEL_BRUTE, PT_ACCEL_BVH = 0, 1, 2
 PT_TIE_REFERENCE, PT_TIE_LOWEST = 0, 1
 
+PT_NOALLOC_MAX_PIXELS = 1 << 18
+
 PT_AUX_PRIMARY_OBJECT, PT_AUX_PRIMARY_FLAT_ID, PT_AUX_PRIMARY_T, PT_AUX_RAY_COUNT = 0, 1, 2, 3
 
 # ---- wire structs as numpy dtypes (align=False; explicit padding) ------------
@@ -97,7 +99,8 @@ assert C.sizeof(PtSettings) == 32 and C.sizeof(PtFrame) == 192 and C.sizeof(PtCo
 # every symbol include/pt_amd.h declares
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_upload_materials",
            "pt_upload_objects", "pt_render", "pt_render_device", "pt_query", "pt_read_aux",
-           "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log", "pt_host_alloc", "pt_host_free"]
+           "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log", "pt_host_alloc", "pt_host_free",
+           "pt_render_device_noalloc"]
 
 LIB_NAME = "libpt_amd.so"
 
@@ -132,6 +135,7 @@ def load_library():
     lib.pt_upload_objects.argtypes = [vp, vp, u32]
     lib.pt_render.argtypes = [vp, C.POINTER(PtFrame), vp]
     lib.pt_render_device.argtypes = [vp, C.POINTER(PtFrame), vp, vp]
+    lib.pt_render_device_noalloc.argtypes = [vp, C.POINTER(PtFrame), vp, vp]
     lib.pt_query.argtypes = [vp, vp, u32, vp]
     lib.pt_read_aux.argtypes = [vp, u32, vp, C.c_size_t]
     lib.pt_set_stats_detail.argtypes = [vp, i32]
@@ -264,6 +268,11 @@ class Context:
         self._check(self._lib.pt_render_device(self._h, C.byref(frame), C.c_void_p(device_ptr),
                                                C.c_void_p(stream) if stream else None))
         self.size = (frame.height, frame.width)
+
+    def render_device_noalloc(self, frame: PtFrame, device_ptr: int, stream: int | None = None):
+        """pt_render_device without device-memory allocation (frames of at most PT_NOALLOC_MAX_PIXELS pixels)."""
+        self._check(self._lib.pt_render_device_noalloc(self._h, C.byref(frame), C.c_void_p(device_ptr),
+                                                       C.c_void_p(stream) if stream else None))
 
     def query(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)

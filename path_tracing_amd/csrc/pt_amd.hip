@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -28,6 +29,23 @@ constexpr uint32_t kTlasMaxRefits = 15;  // object uploads that may refit the TL
 
 thread_local std::string g_create_error;
 
+// ---- work memory of pt_render_device_noalloc -----------------------------------------------------------------------
+// Everything a frame needs besides the scene, its image and the context: path list, parked pixel state, the four aux
+// planes, per-entry cost, per-chunk sweep flags and the work counters, for frames of at most PT_NOALLOC_MAX_PIXELS
+// pixels (sizes rounded up to whole 8x8 tiles). One array per device, part of the code object, held until the process
+// ends; host code only ever uses the address hipGetSymbolAddress returns for the current device (g_scratch_ptr).
+constexpr size_t kNoallocPix = PT_NOALLOC_MAX_PIXELS;
+constexpr size_t kScrRecs = 0;                                         // PathRec[pix]
+constexpr size_t kScrCarry = kScrRecs + sizeof(PathRec) * kNoallocPix;    // PathCarry[pix]
+constexpr size_t kScrAux = kScrCarry + sizeof(PathCarry) * kNoallocPix;   // 4 planes of 4 B
+constexpr size_t kScrCost = kScrAux + 16 * kNoallocPix;                   // u32[pix]
+constexpr size_t kScrSweeps = kScrCost + 4 * kNoallocPix;                 // u32[pix / 64]
+constexpr size_t kScrCounters = kScrSweeps + 4 * (kNoallocPix / 64);      // DCounters
+constexpr size_t kScratchBytes = kScrCounters + ((sizeof(DCounters) + 255) & ~(size_t)255);
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};   // per device: the address of its copy of `scratch`
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -44,6 +62,10 @@ struct DevBuf {
 };
 
 }  // namespace
+
+// The no-allocation work array itself (layout: kScr* above). In host code this name is only a handle for
+// hipGetSymbolAddress; kernels and memsets get the per-device address kept in g_scratch_ptr.
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 // What a frame's per-pixel costs depend on (besides the seeds): compared bytewise.
 struct FrameKey {
@@ -97,6 +119,7 @@ struct pt_ctx {
     bool use_tlas = false;
     std::vector<PtObject> h_objects;  // kept so that a mesh re-upload can rebuild the instance data
 
+    unsigned char* scratch = nullptr;   // this device's no-allocation work array (pt_render_device_noalloc), or null
     uint32_t n_cus = 256;
     uint32_t chunk_pixels = 64;   // see PathParams::chunk
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
@@ -234,6 +257,16 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         }
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb0);
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb1);
+        if (e == hipSuccess && ctx->device < kMaxDevices) {
+            // this device's copy of the no-allocation work array (the device is current here)
+            std::lock_guard<std::mutex> lock(g_scratch_mutex);
+            if (!g_scratch_ptr[ctx->device]) {
+                void* ptr = nullptr;
+                e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+                if (e == hipSuccess) g_scratch_ptr[ctx->device] = static_cast<unsigned char*>(ptr);
+            }
+            ctx->scratch = g_scratch_ptr[ctx->device];
+        }
         if (e != hipSuccess) {
             std::string m = std::string("pt_create: ") + hipGetErrorString(e);
             pt_destroy(ctx);
@@ -718,9 +751,19 @@ int scene_mode(const pt_ctx* ctx, LdsScene* ls) {
     return PT_MODE_LDS;
 }
 
+// Device memory a frame works in besides the scene and its image.
+struct FrameWork {
+    uint32_t *aux_obj, *aux_flat, *aux_rays, *cost, *sweeps_done;
+    float* aux_t;
+    PathRec* recs;
+    PathCarry* carry;
+    DCounters* counters;
+};
+
 // Enqueue one frame on `s`, image to device memory `out`; with `out16` the image is also packed to binary16 there,
-// inside the span the frame's completion event covers.
-int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uint2* out16 = nullptr) {
+// inside the span the frame's completion event covers. `noalloc`: the frame works in the device's static array, keeps no
+// record in the context (no statistics, no aux planes to read back, no schedule hints) and nothing is allocated.
+int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uint2* out16 = nullptr, bool noalloc = false) {
     int rc = check_ready(ctx, "pt_render");
     if (rc != PT_OK) return rc;
     if (f->width == 0 || f->height == 0) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: zero-sized frame");
@@ -728,26 +771,60 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
     const uint32_t pc = f->part_count ? f->part_count : 1u;
     if (f->part_index >= pc) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: part_index >= part_count");
     if (f->settings.samples > (1u << 30)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: more than 2^30 samples per pixel");
-    // This frame's record replaces the one of the frame before the previous one, which has to be complete; the
-    // previous frame may still be running (same stream: its kernels come first). Anything that is not plain
-    // back-to-back rendering on one stream waits for everything.
-    FrameSlot& sl = ctx->slot[ctx->frame_seq & 1];
-    const FrameSlot& prev = ctx->slot[(ctx->frame_seq + 1) & 1];
-    if (s != ctx->last_frame_stream || ctx->stats_detail || prev.detail || !ctx->queue_ahead) rc = finish_timing(ctx);
-    else rc = finish_slot(ctx, sl);
-    if (rc != PT_OK) return rc;
-
     const size_t n_pix = (size_t)f->width * f->height;
-    if ((ctx->aux_w != f->width || ctx->aux_h != f->height) && prev.pending) {   // buffers are about to be re-allocated
-        rc = finish_timing(ctx);
+    const size_t n_padded = (size_t)div_up(f->width, 8) * div_up(f->height, 8) * 64;   // whole 8x8 tiles
+    FrameSlot& sl = ctx->slot[ctx->frame_seq & 1];
+    FrameWork w;
+    if (noalloc) {
+        if (!ctx->scratch) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: no work array on this device");
+        if (n_padded > kNoallocPix)
+            return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: frame larger than PT_NOALLOC_MAX_PIXELS (" + std::to_string(kNoallocPix) +
+                                                     " pixels, sizes rounded up to multiples of 8); use pt_render_device");
+        if (f->flags != 0u) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: frame flags are not supported");
+        rc = finish_timing(ctx);   // frames of the allocating entry points still in flight: their records are read first
         if (rc != PT_OK) return rc;
+        unsigned char* b = ctx->scratch;
+        w.recs = reinterpret_cast<PathRec*>(b + kScrRecs);
+        w.carry = reinterpret_cast<PathCarry*>(b + kScrCarry);
+        w.aux_obj = reinterpret_cast<uint32_t*>(b + kScrAux);
+        w.aux_flat = w.aux_obj + kNoallocPix;
+        w.aux_t = reinterpret_cast<float*>(w.aux_obj + 2 * kNoallocPix);
+        w.aux_rays = w.aux_obj + 3 * kNoallocPix;
+        w.cost = reinterpret_cast<uint32_t*>(b + kScrCost);
+        w.sweeps_done = reinterpret_cast<uint32_t*>(b + kScrSweeps);
+        w.counters = reinterpret_cast<DCounters*>(b + kScrCounters);
+        ctx->aux_w = ctx->aux_h = 0;   // the context's aux planes no longer describe the last frame
+    } else {
+        // This frame's record replaces the one of the frame before the previous one, which has to be complete; the
+        // previous frame may still be running (same stream: its kernels come first). Anything that is not plain
+        // back-to-back rendering on one stream waits for everything.
+        const FrameSlot& prev = ctx->slot[(ctx->frame_seq + 1) & 1];
+        if (s != ctx->last_frame_stream || ctx->stats_detail || prev.detail || !ctx->queue_ahead) rc = finish_timing(ctx);
+        else rc = finish_slot(ctx, sl);
+        if (rc != PT_OK) return rc;
+        if ((ctx->aux_w != f->width || ctx->aux_h != f->height) && prev.pending) {   // buffers are about to be re-allocated
+            rc = finish_timing(ctx);
+            if (rc != PT_OK) return rc;
+        }
+        PT_HIP(ctx, ctx->d_aux_obj.ensure(4 * n_pix));
+        PT_HIP(ctx, ctx->d_aux_flat.ensure(4 * n_pix));
+        PT_HIP(ctx, ctx->d_aux_t.ensure(4 * n_pix));
+        PT_HIP(ctx, ctx->d_aux_rays.ensure(4 * n_pix));
+        ctx->aux_w = f->width;
+        ctx->aux_h = f->height;
+        // path list: at most one entry per pixel (of this partition: sized for the whole frame, partitions are rare)
+        PT_HIP(ctx, ctx->d_paths.ensure(sizeof(PathRec) * n_padded));
+        PT_HIP(ctx, ctx->d_cost.ensure(sizeof(uint32_t) * n_padded));
+        w.aux_obj = ctx->d_aux_obj.as<uint32_t>();
+        w.aux_flat = ctx->d_aux_flat.as<uint32_t>();
+        w.aux_t = ctx->d_aux_t.as<float>();
+        w.aux_rays = ctx->d_aux_rays.as<uint32_t>();
+        w.recs = ctx->d_paths.as<PathRec>();
+        w.cost = ctx->d_cost.as<uint32_t>();
+        w.counters = sl.counters.as<DCounters>();
+        w.sweeps_done = nullptr;   // allocated below, when the frame runs in sweeps
+        w.carry = nullptr;
     }
-    PT_HIP(ctx, ctx->d_aux_obj.ensure(4 * n_pix));
-    PT_HIP(ctx, ctx->d_aux_flat.ensure(4 * n_pix));
-    PT_HIP(ctx, ctx->d_aux_t.ensure(4 * n_pix));
-    PT_HIP(ctx, ctx->d_aux_rays.ensure(4 * n_pix));
-    ctx->aux_w = f->width;
-    ctx->aux_h = f->height;
 
     FrameParams fp;
     std::memcpy(fp.wfv, f->world_from_view, sizeof fp.wfv);
@@ -766,17 +843,14 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
     fp.tiles_y = div_up(f->height, 8);
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     fp.n_local_tiles = (f->part_index < n_tiles) ? (n_tiles - f->part_index + pc - 1) / pc : 0u;
-    PT_HIP(ctx, hipMemsetAsync(sl.counters.p, 0, sizeof(DCounters), s));
+    PT_HIP(ctx, hipMemsetAsync(w.counters, 0, sizeof(DCounters), s));
     if (pc > 1) {
         PT_HIP(ctx, hipMemsetAsync(out, 0, 16 * n_pix, s));
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_obj.p, 0xFF, 4 * n_pix, s));
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_flat.p, 0xFF, 4 * n_pix, s));
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_t.p, 0, 4 * n_pix, s));
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_aux_rays.p, 0, 4 * n_pix, s));
+        PT_HIP(ctx, hipMemsetAsync(w.aux_obj, 0xFF, 4 * n_pix, s));
+        PT_HIP(ctx, hipMemsetAsync(w.aux_flat, 0xFF, 4 * n_pix, s));
+        PT_HIP(ctx, hipMemsetAsync(w.aux_t, 0, 4 * n_pix, s));
+        PT_HIP(ctx, hipMemsetAsync(w.aux_rays, 0, 4 * n_pix, s));
     }
-    // path list: at most one entry per pixel of this partition
-    PT_HIP(ctx, ctx->d_paths.ensure(sizeof(PathRec) * (size_t)fp.n_local_tiles * 64));
-    PT_HIP(ctx, ctx->d_cost.ensure(sizeof(uint32_t) * (size_t)fp.n_local_tiles * 64));
     // Per-pixel ray counts of the previous frame, still in the aux plane, predict what this frame's pixels cost when
     // it is the same view of the same scene (the usual case: a renderer that draws frame after frame). They only
     // decide the order in which k_paths takes the pixels, never a result.
@@ -788,22 +862,22 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
     key.part_index = f->part_index; key.part_count = pc;
     std::memcpy(key.wfv, f->world_from_view, sizeof key.wfv);
     std::memcpy(key.vfc, f->view_from_clip, sizeof key.vfc);
-    const bool use_hint = ctx->hint_valid && std::memcmp(&key, &ctx->hint_key, sizeof key) == 0 && ctx->cost_hints &&
+    const bool use_hint = !noalloc && ctx->hint_valid && std::memcmp(&key, &ctx->hint_key, sizeof key) == 0 && ctx->cost_hints &&
                           f->settings.samples >= 8u && f->settings.bounces > 1u;
     ctx->hint_valid = false;   // until this frame has been enqueued completely
     SceneView sv = make_view(ctx);
     const uint32_t depth = stack_depth_needed(ctx);
-    const bool st = ctx->stats_detail;
-    sl.detail = st;
+    const bool st = ctx->stats_detail && !noalloc;
+    if (!noalloc) sl.detail = st;
     float4* o4 = reinterpret_cast<float4*>(out);
-    uint32_t* ao = ctx->d_aux_obj.as<uint32_t>();
-    uint32_t* af = ctx->d_aux_flat.as<uint32_t>();
-    float* at = ctx->d_aux_t.as<float>();
-    uint32_t* ar = ctx->d_aux_rays.as<uint32_t>();
-    PathRec* recs = ctx->d_paths.as<PathRec>();
-    DCounters* dc = sl.counters.as<DCounters>();
+    uint32_t* ao = w.aux_obj;
+    uint32_t* af = w.aux_flat;
+    float* at = w.aux_t;
+    uint32_t* ar = w.aux_rays;
+    PathRec* recs = w.recs;
+    DCounters* dc = w.counters;
 
-    PT_HIP(ctx, hipEventRecord(sl.ev0, s));
+    if (!noalloc) PT_HIP(ctx, hipEventRecord(sl.ev0, s));
     // 1. primary pass: one wave per tile
     LdsScene ls;
     const int mode = scene_mode(ctx, &ls);
@@ -819,14 +893,14 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             {{k_primary<PT_MODE_TLAS, false, 4>, k_primary<PT_MODE_TLAS, false, 16>}, {k_primary<PT_MODE_TLAS, true, 4>, k_primary<PT_MODE_TLAS, true, 16>}},
             {{k_primary<PT_MODE_LDS, false, 4>, k_primary<PT_MODE_LDS, false, 16>}, {k_primary<PT_MODE_LDS, true, 4>, k_primary<PT_MODE_LDS, true, 16>}}};
         if (grid) {
-            table[mode][st ? 1 : 0][wide ? 1 : 0]<<<grid, waves * 64, lds, s>>>(PT_SCENE_ARGS(sv), ls, fp, depth, o4, ao, af, at, ar, recs, ctx->d_cost.as<uint32_t>(), use_hint ? 1u : 0u, dc);
+            table[mode][st ? 1 : 0][wide ? 1 : 0]<<<grid, waves * 64, lds, s>>>(PT_SCENE_ARGS(sv), ls, fp, depth, o4, ao, af, at, ar, recs, w.cost, use_hint ? 1u : 0u, dc);
             PT_HIP(ctx, hipGetLastError());
         }
     }
     if (st) {
         PT_HIP(ctx, hipMemcpyAsync(sl.counters_k1.p, sl.counters.p, sizeof(DCounters), hipMemcpyDeviceToDevice, s));
     }
-    PT_HIP(ctx, hipEventRecord(sl.evm, s));
+    if (!noalloc) PT_HIP(ctx, hipEventRecord(sl.evm, s));
     // 2. path pass: persistent waves, as many workgroups as fit on the chip at once (fewer for small frames); they
     //    pull list entries from a counter until the list is exhausted
     if (fp.bounces > 0 && fp.samples > 0 && fp.n_local_tiles) {
@@ -898,9 +972,13 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         }
         if (pp.n_sweeps > 1u) {
             const size_t bytes = sizeof(uint32_t) * (size_t)fp.n_local_tiles;   // one flag per chunk of 64 entries
-            PT_HIP(ctx, ctx->d_sweeps_done.ensure(bytes));
-            PT_HIP(ctx, hipMemsetAsync(ctx->d_sweeps_done.p, 0, bytes, s));
-            PT_HIP(ctx, ctx->d_carry.ensure(sizeof(PathCarry) * (size_t)fp.n_local_tiles * 64));
+            if (!noalloc) {
+                PT_HIP(ctx, ctx->d_sweeps_done.ensure(bytes));
+                PT_HIP(ctx, ctx->d_carry.ensure(sizeof(PathCarry) * (size_t)fp.n_local_tiles * 64));
+                w.sweeps_done = ctx->d_sweeps_done.as<uint32_t>();
+                w.carry = ctx->d_carry.as<PathCarry>();
+            }
+            PT_HIP(ctx, hipMemsetAsync(w.sweeps_done, 0, bytes, s));
         }
         uint4* wlog = nullptr;
         ctx->wave_log_records = 0;
@@ -919,15 +997,16 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             PT_HIP(ctx, ctx->d_chunk_order.ensure(sizeof(uint32_t) * max_chunks + sizeof(ChunkOrderInfo)));
             uint32_t* order = ctx->d_chunk_order.as<uint32_t>();
             ChunkOrderInfo* info = reinterpret_cast<ChunkOrderInfo*>(order + max_chunks);
-            k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(ctx->d_cost.as<uint32_t>(), dc, fp.samples, ctx->d_chunk_bin.as<uint32_t>());
+            k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(w.cost, dc, fp.samples, ctx->d_chunk_bin.as<uint32_t>());
             k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info);
             chunk_order = order;
             order_info = info;
         }
-        fn<<<grid, 256, lds_paths, s>>>(PT_SCENE_ARGS(sv), ls, lb, pp, depth, recs, ctx->d_carry.as<PathCarry>(), ctx->d_sweeps_done.as<uint32_t>(), chunk_order,
+        fn<<<grid, 256, lds_paths, s>>>(PT_SCENE_ARGS(sv), ls, lb, pp, depth, recs, w.carry, w.sweeps_done, chunk_order,
                                   order_info, o4, ar, dc, wlog);
         PT_HIP(ctx, hipGetLastError());
     }
+    if (noalloc) return PT_OK;   // (no record of this frame is kept; hint_valid stays false)
     ctx->hint_key = key;
     ctx->hint_valid = f->settings.samples > 0u && f->settings.bounces > 0u;
     // pixels of this partition
@@ -995,6 +1074,21 @@ int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device, v
         return PT_OK;
     } catch (...) {
         return fail(ctx, PT_ERR_DEVICE, "pt_render_device: unexpected exception");
+    }
+}
+
+int pt_render_device_noalloc(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device, void* hip_stream) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!frame || !out_rgba_device) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_device_noalloc: null argument");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
+        int rc = render_enqueue(ctx, frame, reinterpret_cast<float*>(out_rgba_device), s, nullptr, true);
+        if (rc != PT_OK) return rc;
+        if (!hip_stream) PT_HIP(ctx, hipStreamSynchronize(s));
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_render_device_noalloc: unexpected exception");
     }
 }
 

@@ -175,6 +175,8 @@ extern "C" {
     pub fn pt_upload_objects(ctx: *mut pt_ctx, objects: *const PtObject, n_objects: u32) -> c_int;
     pub fn pt_render(ctx: *mut pt_ctx, frame: *const PtFrame, out_rgba_host: *mut c_void) -> c_int;
     pub fn pt_render_device(ctx: *mut pt_ctx, frame: *const PtFrame, out_rgba_device: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    /// The same frame without device-memory allocation (frames of at most PT_NOALLOC_MAX_PIXELS pixels).
+    pub fn pt_render_device_noalloc(ctx: *mut pt_ctx, frame: *const PtFrame, out_rgba_device: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn pt_host_alloc(ctx: *mut pt_ctx, bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
     pub fn pt_host_free(ctx: *mut pt_ctx, ptr: *mut c_void) -> c_int;
     pub fn pt_query(ctx: *mut pt_ctx, rays_host: *const PtRay, n_rays: u32, hits_host: *mut PtHit) -> c_int;
