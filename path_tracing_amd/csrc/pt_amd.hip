@@ -99,21 +99,25 @@ struct pt_ctx {
     // uploaded wire arrays (device copies)
     DevBuf w_meshes, w_indices, w_vertices, w_objects;
     // traversal layout
-    DevBuf d_meshes, d_tris, d_attrs, d_tri_lo, d_tri_hi, d_blas_nodes;
-    DevBuf d_objects, d_obj_lo, d_obj_hi, d_tlas_nodes, d_tri_base;
+    DevBuf d_meshes, d_tris, d_tri_ids, d_attrs, d_tri_lo, d_tri_hi, d_blas_nodes, d_blas_bnodes, d_blas_order;
+    DevBuf d_objects, d_obj_l2w, d_obj_lo, d_obj_hi, d_tlas_nodes, d_tlas_bnodes, d_tri_base;
     DevBuf d_materials, d_textures, d_texdata;
     // scratch for uploads / builds
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
-        t_bounds, t_info, t_errors;
+        t_bounds, t_info, t_errors, t_ranges, t_work, t_tris_tmp;
     // frame outputs
     DevBuf d_out, d_out16, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_rays, d_hits, d_paths, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
+    std::vector<uint32_t> h_blas_n_wide;      // per mesh: nodes of its (4-wide) BLAS
     uint32_t n_meshes = 0, n_tris = 0, n_objects = 0, n_materials = 0, n_textures = 0, n_texdata = 0;
     uint32_t n_blas_nodes = 0;
     uint32_t obj_max_mesh = 0, obj_max_mat = 0;
-    uint32_t max_blas_depth = 0, tlas_depth = 0, tlas_root = PT_NONE;
+    uint32_t max_blas_depth = 0, tlas_depth = 0, tlas_root = PT_NONE;   // depths: levels of the 4-wide trees
+    uint32_t max_blas_need = 0, tlas_need = 0;   // traversal stack entries a BLAS / the TLAS walk can need
+    uint32_t tlas_n_wide = 0;                    // nodes of the TLAS
+    uint32_t tlas_top_max = 128;                 // nodes of its top levels k_paths stages in LDS at most
     bool have_meshes = false, have_materials = false, have_objects = false;
     bool objects_built = false;   // the instance data on the device was derived from h_objects and the current meshes
     bool use_tlas = false;
@@ -129,6 +133,7 @@ struct pt_ctx {
     bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
     uint64_t last_n_paths = ~0ull; // entries of the path list of the last frame read back
     uint32_t walk_quota = 16;     // see PathParams::walk_quota
+    uint32_t blas_max_leaf = PT_WIDE_MAX_LEAF;   // triangles a BLAS leaf holds at most (1..4)
     bool split_chunks = false;    // see PathParams::split_chunks: shorter single frames on scenes of long BVH walks, fewer frames per second when several are in flight
     bool lds_blas = true;         // object-list scenes: stage the biggest BLAS that fits in LDS (k_paths)
     uint32_t lds_per_cu = 160 * 1024;
@@ -167,8 +172,10 @@ inline bool finite3(const float* v) { return std::isfinite(v[0]) && std::isfinit
 
 // ---- LBVH over n boxes box_lo/hi[first .. first+n) -> nodes[0 .. n-1) ----------------------
 // Child references to internal nodes are node_base + index; depth goes to info_slot (device).
+// leaf_is_pos: leaves are referenced by sorted position (BLAS) instead of by primitive number (TLAS); then the ranges of
+// sorted positions below every node are kept in t_ranges for the collapse.
 int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t first, uint32_t n, BvhNode* nodes,
-               uint32_t node_base, uint32_t* info_slot) {
+               uint32_t node_base, uint32_t* info_slot, bool leaf_is_pos) {
     hipStream_t s = ctx->stream;
     const uint32_t n_blocks = div_up(n, RS_KEYS);
     PT_HIP(ctx, ctx->t_keys0.ensure(sizeof(uint32_t) * n));
@@ -180,6 +187,7 @@ int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t
     PT_HIP(ctx, ctx->t_par_leaf.ensure(sizeof(uint32_t) * n));
     PT_HIP(ctx, ctx->t_arrive.ensure(sizeof(uint32_t) * n));
     PT_HIP(ctx, ctx->t_bounds.ensure(sizeof(uint32_t) * 8));
+    if (leaf_is_pos) PT_HIP(ctx, ctx->t_ranges.ensure(sizeof(uint2) * n));
 
     uint32_t* bounds = ctx->t_bounds.as<uint32_t>();
     PT_HIP(ctx, hipMemsetAsync(bounds, 0xFF, 12, s));
@@ -201,8 +209,19 @@ int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t
     uint32_t* par_leaf = ctx->t_par_leaf.as<uint32_t>();
     uint32_t* arrive = ctx->t_arrive.as<uint32_t>();
     PT_HIP(ctx, hipMemsetAsync(arrive, 0, sizeof(uint32_t) * n, s));
-    k_karras<<<div_up(n - 1, 256), 256, 0, s>>>(k0, n, par_int, par_leaf);
-    k_fit<<<div_up(n, 256), 256, 0, s>>>(box_lo, box_hi, first, v0, n, par_int, par_leaf, arrive, nodes, node_base, info_slot);
+    k_karras<<<div_up(n - 1, 256), 256, 0, s>>>(k0, n, par_int, par_leaf, leaf_is_pos ? ctx->t_ranges.as<uint2>() : nullptr);
+    k_fit<<<div_up(n, 256), 256, 0, s>>>(box_lo, box_hi, first, v0, n, par_int, par_leaf, arrive, nodes, node_base, info_slot, leaf_is_pos ? 1u : 0u);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// The 4-wide tree the rays walk, from a binary tree of n - 1 nodes over n primitives (k_collapse). info (device):
+// {nodes, levels, root reference, stack entries a walk can need}.
+int collapse_wide(pt_ctx* ctx, const BvhNode* bnodes, uint32_t bnode_base, uint32_t n, bool blas, WNode* wnodes, uint32_t wnode_base,
+                  uint32_t* info) {
+    PT_HIP(ctx, ctx->t_work.ensure(sizeof(uint2) * (size_t)std::max<uint32_t>(n, 1)));
+    k_collapse<<<1, 1024, 0, ctx->stream>>>(bnodes, bnode_base, n, blas ? ctx->t_ranges.as<uint2>() : nullptr, ctx->blas_max_leaf, wnodes, wnode_base,
+                                            ctx->t_work.as<uint2>(), info);
     PT_HIP(ctx, hipGetLastError());
     return PT_OK;
 }
@@ -239,6 +258,8 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
         if (std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = true;
         if (const char* e = std::getenv("PT_AMD_WALK_QUOTA")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->walk_quota = (uint32_t)v; }
+        if (const char* e = std::getenv("PT_AMD_BLAS_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= (int)PT_WIDE_MAX_LEAF) ctx->blas_max_leaf = (uint32_t)v; }
+        if (const char* e = std::getenv("PT_AMD_TLAS_TOP")) { int v = std::atoi(e); if (v >= 0 && v <= 2048) ctx->tlas_top_max = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_LDS_BLAS")) ctx->lds_blas = false;
         if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
         if (std::getenv("PT_AMD_NO_QUEUE_AHEAD")) ctx->queue_ahead = false;
@@ -294,7 +315,8 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_out16, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
-                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log};
+                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log,
+                      &ctx->d_tri_ids, &ctx->d_blas_bnodes, &ctx->d_blas_order, &ctx->d_obj_l2w, &ctx->d_tlas_bnodes, &ctx->t_ranges, &ctx->t_work, &ctx->t_tris_tmp};
     for (DevBuf* b : bufs) b->release();
     for (void* p : ctx->host_allocs) (void)hipHostFree(p);
     for (FrameSlot& sl : ctx->slot) {
@@ -369,7 +391,7 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
             d.tri_first = acc;
             d.tri_count = me.tri_count;
             d.blas_root = PT_NONE;
-            d.blas_depth = 0;
+            d.blas_need = 0;
             d.max_abs = std::isfinite(ma) ? ma : 0.0f;
             d._pad = 0;
             mesh_first[m] = acc;
@@ -392,8 +414,11 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
         PT_HIP(ctx, ctx->d_tri_hi.ensure(sizeof(float4) * (size_t)n_tris));
         PT_HIP(ctx, ctx->t_tri_mesh.ensure(sizeof(uint32_t) * (size_t)n_tris));
         PT_HIP(ctx, ctx->t_mesh_first.ensure(sizeof(uint32_t) * (size_t)n_meshes));
-        PT_HIP(ctx, ctx->d_blas_nodes.ensure(sizeof(BvhNode) * (size_t)n_nodes));
-        PT_HIP(ctx, ctx->t_info.ensure(sizeof(uint32_t) * (size_t)(n_meshes + 1)));
+        PT_HIP(ctx, ctx->d_blas_bnodes.ensure(sizeof(BvhNode) * (size_t)n_nodes));   // binary trees: what the build makes first
+        PT_HIP(ctx, ctx->d_blas_nodes.ensure(sizeof(WNode) * (size_t)n_nodes));       // the 4-wide trees the rays walk (never more nodes)
+        PT_HIP(ctx, ctx->d_blas_order.ensure(sizeof(uint32_t) * (size_t)n_tris));
+        PT_HIP(ctx, ctx->d_tri_ids.ensure(sizeof(uint32_t) * (size_t)n_tris));
+        PT_HIP(ctx, ctx->t_info.ensure(sizeof(uint32_t) * 8 * (size_t)(n_meshes + 1)));   // per mesh (and one for the TLAS): binary depth, -, -, -, collapse info[4]
         if (n_meshes) PT_HIP(ctx, hipMemcpyAsync(ctx->w_meshes.p, meshes, sizeof(PtMesh) * (size_t)n_meshes, hipMemcpyHostToDevice, s));
         if (n_indices) PT_HIP(ctx, hipMemcpyAsync(ctx->w_indices.p, indices, sizeof(uint32_t) * (size_t)n_indices, hipMemcpyHostToDevice, s));
         if (n_vertices) PT_HIP(ctx, hipMemcpyAsync(ctx->w_vertices.p, vertices, sizeof(PtVertex) * (size_t)n_vertices, hipMemcpyHostToDevice, s));
@@ -405,26 +430,45 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
                                                              ctx->w_vertices.as<WVertex>(), n_tris, ctx->d_tris.as<DTri>(),
                                                              ctx->d_attrs.as<DTriAttr>(), ctx->d_tri_lo.as<float4>(),
                                                              ctx->d_tri_hi.as<float4>());
+            k_iota<<<div_up(n_tris, 256), 256, 0, s>>>(ctx->d_tri_ids.as<uint32_t>(), n_tris);   // (meshes without a BLAS keep their own order)
             PT_HIP(ctx, hipGetLastError());
         }
-        PT_HIP(ctx, hipMemsetAsync(ctx->t_info.p, 0, sizeof(uint32_t) * (size_t)(n_meshes + 1), s));
+        PT_HIP(ctx, hipMemsetAsync(ctx->t_info.p, 0, sizeof(uint32_t) * 8 * (size_t)(n_meshes + 1), s));
         for (uint32_t m = 0; m < n_meshes; ++m) {
             if (node_base[m] == PT_NONE) continue;
-            int rc = build_lbvh(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), hm[m].tri_first, hm[m].tri_count,
-                                ctx->d_blas_nodes.as<BvhNode>() + node_base[m], node_base[m], ctx->t_info.as<uint32_t>() + m);
+            const uint32_t first = hm[m].tri_first, cnt = hm[m].tri_count;
+            uint32_t* info = ctx->t_info.as<uint32_t>() + 8 * (size_t)m;
+            BvhNode* bn = ctx->d_blas_bnodes.as<BvhNode>() + node_base[m];
+            int rc = build_lbvh(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), first, cnt, bn, node_base[m], info, true);
             if (rc != PT_OK) return rc;
-            hm[m].blas_root = node_base[m];
+            // the mesh's triangle records in the order of the tree's leaves, and which triangle each one is
+            PT_HIP(ctx, ctx->t_tris_tmp.ensure(sizeof(DTri) * (size_t)cnt));
+            k_permute_tris<<<div_up(cnt, 256), 256, 0, s>>>(ctx->d_tris.as<DTri>() + first, ctx->t_vals0.as<uint32_t>(), cnt, ctx->t_tris_tmp.as<DTri>(),
+                                                            ctx->d_tri_ids.as<uint32_t>() + first);
+            PT_HIP(ctx, hipGetLastError());
+            PT_HIP(ctx, hipMemcpyAsync(ctx->d_tris.as<DTri>() + first, ctx->t_tris_tmp.p, sizeof(DTri) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
+            PT_HIP(ctx, hipMemcpyAsync(ctx->d_blas_order.as<uint32_t>() + first, ctx->t_vals0.p, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
+            rc = collapse_wide(ctx, bn, node_base[m], cnt, true, ctx->d_blas_nodes.as<WNode>() + node_base[m], node_base[m], info + 4);
+            if (rc != PT_OK) return rc;
         }
-        std::vector<uint32_t> depths(n_meshes + 1, 0);
-        PT_HIP(ctx, hipMemcpyAsync(depths.data(), ctx->t_info.p, sizeof(uint32_t) * (size_t)(n_meshes + 1), hipMemcpyDeviceToHost, s));
+        std::vector<uint32_t> infos(8 * (size_t)(n_meshes + 1), 0);
+        PT_HIP(ctx, hipMemcpyAsync(infos.data(), ctx->t_info.p, sizeof(uint32_t) * infos.size(), hipMemcpyDeviceToHost, s));
         PT_HIP(ctx, hipStreamSynchronize(s));
-        uint32_t max_depth = 0;
+        uint32_t max_depth = 0, max_need = 0;
+        std::vector<uint32_t> n_wide(n_meshes, 0);
         for (uint32_t m = 0; m < n_meshes; ++m) {
-            hm[m].blas_depth = depths[m];
-            if (node_base[m] != PT_NONE) max_depth = std::max(max_depth, depths[m]);
+            if (node_base[m] == PT_NONE) continue;
+            const uint32_t* ci = &infos[8 * (size_t)m + 4];
+            n_wide[m] = ci[0];
+            hm[m].blas_root = ci[2];
+            hm[m].blas_need = ci[3];
+            max_depth = std::max(max_depth, ci[1]);
+            max_need = std::max(max_need, ci[3]);
         }
         if (n_meshes) PT_HIP(ctx, hipMemcpyAsync(ctx->d_meshes.p, hm.data(), sizeof(DMesh) * (size_t)n_meshes, hipMemcpyHostToDevice, s));
         PT_HIP(ctx, hipStreamSynchronize(s));
+        ctx->h_blas_n_wide.swap(n_wide);
+        ctx->max_blas_need = max_need;
         ctx->h_meshes.swap(hm);
         ctx->h_blas_nodes_base.swap(node_base);
         ctx->n_meshes = n_meshes;
@@ -549,6 +593,8 @@ int rebuild_objects(pt_ctx* ctx) {
     ctx->n_objects = n;
     ctx->tlas_root = PT_NONE;
     ctx->tlas_depth = 0;
+    ctx->tlas_need = 0;
+    ctx->tlas_n_wide = 0;
     ctx->use_tlas = false;
     ctx->stats.build_ms = 0.0;
     ctx->objects_built = false;
@@ -556,43 +602,46 @@ int rebuild_objects(pt_ctx* ctx) {
 
     PT_HIP(ctx, ctx->w_objects.ensure(sizeof(PtObject) * (size_t)n));
     PT_HIP(ctx, ctx->d_objects.ensure(sizeof(DObject) * (size_t)n));
+    PT_HIP(ctx, ctx->d_obj_l2w.ensure(sizeof(Affine) * (size_t)n));
     PT_HIP(ctx, ctx->d_obj_lo.ensure(sizeof(float4) * (size_t)n));
     PT_HIP(ctx, ctx->d_obj_hi.ensure(sizeof(float4) * (size_t)n));
     PT_HIP(ctx, ctx->d_tri_base.ensure(sizeof(uint32_t) * (size_t)n));
-    PT_HIP(ctx, ctx->t_info.ensure(sizeof(uint32_t) * (size_t)(ctx->n_meshes + 1)));
+    PT_HIP(ctx, ctx->t_info.ensure(sizeof(uint32_t) * 8 * (size_t)(ctx->n_meshes + 1)));
     PT_HIP(ctx, hipMemcpyAsync(ctx->w_objects.p, ctx->h_objects.data(), sizeof(PtObject) * (size_t)n, hipMemcpyHostToDevice, s));
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_tri_base.p, tri_base.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     PT_HIP(ctx, hipEventRecord(ctx->evb0, s));
     k_prep_objects<<<div_up(n, 256), 256, 0, s>>>(ctx->w_objects.as<WObject>(), ctx->d_tri_base.as<uint32_t>(),
-                                                  ctx->d_meshes.as<DMesh>(), n, ctx->d_objects.as<DObject>(),
+                                                  ctx->d_meshes.as<DMesh>(), n, ctx->d_objects.as<DObject>(), ctx->d_obj_l2w.as<Affine>(),
                                                   ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>());
     PT_HIP(ctx, hipGetLastError());
     const bool want_tlas = (ctx->cfg.accel == PT_ACCEL_BVH) || (ctx->cfg.accel == PT_ACCEL_AUTO && n > kTlasMinObjects);
-    uint32_t depth = 0;
+    uint32_t cinfo[4] = {0, 0, PT_NONE, 0};   // collapse info: nodes, levels, root, stack need
     bool refitted = false;
     if (!want_tlas || n < 2) ctx->tlas_built_n = 0;
     if (want_tlas) {
         if (n == 1) {
-            ctx->tlas_root = PT_LEAF_BIT | 0u;
+            cinfo[2] = PT_LEAF_BIT | 0u;
         } else {
-            uint32_t* slot = ctx->t_info.as<uint32_t>() + ctx->n_meshes;
-            PT_HIP(ctx, hipMemsetAsync(slot, 0, sizeof(uint32_t), s));
+            uint32_t* slot = ctx->t_info.as<uint32_t>() + 8 * (size_t)ctx->n_meshes;
+            PT_HIP(ctx, hipMemsetAsync(slot, 0, 8 * sizeof(uint32_t), s));
             const size_t nb = sizeof(uint32_t) * (size_t)n;
-            // Same number of objects as the tree was built for: keep its topology (leaf order and parent links) and
-            // only fit the boxes again, bottom-up. Any valid tree gives the same image; a stale topology only costs
-            // traversal steps, so a fresh build is made every kTlasMaxRefits updates.
+            // Same number of objects as the tree was built for: keep the binary tree's topology (leaf order and parent
+            // links) and only fit the boxes again, bottom-up. Any valid tree gives the same image; a stale topology only
+            // costs traversal steps, so a fresh build is made every kTlasMaxRefits updates. The 4-wide tree is made
+            // from the binary one either way.
             if (ctx->allow_refit && ctx->tlas_built_n == n && ctx->tlas_refits < kTlasMaxRefits) {
                 PT_HIP(ctx, ctx->t_arrive.ensure(nb));
                 PT_HIP(ctx, hipMemsetAsync(ctx->t_arrive.p, 0, nb, s));
                 k_fit<<<div_up(n, 256), 256, 0, s>>>(ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, ctx->d_tlas_order.as<uint32_t>(), n,
                                                      ctx->d_tlas_par_int.as<uint32_t>(), ctx->d_tlas_par_leaf.as<uint32_t>(),
-                                                     ctx->t_arrive.as<uint32_t>(), ctx->d_tlas_nodes.as<BvhNode>(), 0, slot);
+                                                     ctx->t_arrive.as<uint32_t>(), ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, 0u);
                 PT_HIP(ctx, hipGetLastError());
                 ctx->tlas_refits++;
                 refitted = true;
             } else {
-                PT_HIP(ctx, ctx->d_tlas_nodes.ensure(sizeof(BvhNode) * (size_t)(n - 1)));
-                int rc = build_lbvh(ctx, ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_nodes.as<BvhNode>(), 0, slot);
+                PT_HIP(ctx, ctx->d_tlas_bnodes.ensure(sizeof(BvhNode) * (size_t)(n - 1)));
+                PT_HIP(ctx, ctx->d_tlas_nodes.ensure(sizeof(WNode) * (size_t)(n - 1)));
+                int rc = build_lbvh(ctx, ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false);
                 if (rc != PT_OK) return rc;
                 PT_HIP(ctx, ctx->d_tlas_order.ensure(nb));
                 PT_HIP(ctx, ctx->d_tlas_par_int.ensure(nb));
@@ -603,8 +652,9 @@ int rebuild_objects(pt_ctx* ctx) {
                 ctx->tlas_built_n = n;
                 ctx->tlas_refits = 0;
             }
-            PT_HIP(ctx, hipMemcpyAsync(&depth, slot, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            ctx->tlas_root = 0;
+            int rc = collapse_wide(ctx, ctx->d_tlas_bnodes.as<BvhNode>(), 0, n, false, ctx->d_tlas_nodes.as<WNode>(), 0, slot + 4);
+            if (rc != PT_OK) return rc;
+            PT_HIP(ctx, hipMemcpyAsync(cinfo, slot + 4, sizeof cinfo, hipMemcpyDeviceToHost, s));
         }
         ctx->use_tlas = true;
     }
@@ -612,19 +662,22 @@ int rebuild_objects(pt_ctx* ctx) {
     PT_HIP(ctx, hipStreamSynchronize(s));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, ctx->evb0, ctx->evb1) == hipSuccess) ctx->stats.build_ms = ms;
-    ctx->tlas_depth = depth;
+    ctx->tlas_n_wide = cinfo[0];
+    ctx->tlas_depth = cinfo[1];
+    ctx->tlas_root = want_tlas ? cinfo[2] : PT_NONE;
+    ctx->tlas_need = cinfo[3];
     ctx->tlas_refitted = refitted;
     ctx->objects_built = true;
     return PT_OK;
 }
 
-// Entries of the per-lane traversal stack. A tree's depth is the number of internal nodes on its longest root-to-leaf
-// path; a walk pushes at most one entry per internal node it descends through, and a BLAS walk starts on top of
-// what the TLAS walk has pushed, so the depths add up. (LDS per workgroup decides how many fit on a compute unit.)
+// Entries of the per-lane traversal stack: what a TLAS walk can hold (the children it has put aside on its way down,
+// counted exactly when the tree is made) plus what the walk of the deepest BLAS adds on top of it, plus the three words
+// of headroom wide_visit() writes into. (LDS per workgroup decides how many workgroups fit on a compute unit.)
 uint32_t stack_depth_needed(const pt_ctx* ctx) {
-    uint32_t d = ctx->max_blas_depth;
-    if (ctx->use_tlas) d += ctx->tlas_depth;
-    return std::max<uint32_t>(d, 2);
+    uint32_t d = ctx->max_blas_need;
+    if (ctx->use_tlas) d += ctx->tlas_need;
+    return d + 3u;
 }
 
 int check_ready(pt_ctx* ctx, const char* who) {
@@ -642,11 +695,13 @@ int check_ready(pt_ctx* ctx, const char* who) {
 SceneView make_view(const pt_ctx* ctx) {
     SceneView v;
     v.objects = ctx->d_objects.as<DObject>();
+    v.obj_l2w = ctx->d_obj_l2w.as<Affine>();
     v.meshes = ctx->d_meshes.as<DMesh>();
     v.tris = ctx->d_tris.as<DTri>();
+    v.tri_ids = ctx->d_tri_ids.as<uint32_t>();
     v.tri_attrs = ctx->d_attrs.as<DTriAttr>();
-    v.blas_nodes = ctx->d_blas_nodes.as<BvhNode>();
-    v.tlas_nodes = ctx->d_tlas_nodes.as<BvhNode>();
+    v.blas_nodes = ctx->d_blas_nodes.as<WNode>();
+    v.tlas_nodes = ctx->d_tlas_nodes.as<WNode>();
     v.obj_lo = ctx->d_obj_lo.as<float4>();
     v.obj_hi = ctx->d_obj_hi.as<float4>();
     v.materials = ctx->d_materials.as<DMaterial>();
@@ -659,6 +714,10 @@ SceneView make_view(const pt_ctx* ctx) {
     v.cull_boxes = (ctx->cfg.accel == PT_ACCEL_BRUTE) ? 0u : 1u;
     v._pad0 = 0;
     v._pad1 = 0;
+    v.obj_slab = nullptr;
+    v.lb_nodes = nullptr; v.lb_tris = nullptr; v.lb_tri_ids = nullptr;
+    v.lb_mesh = PT_NONE; v.lb_node_base = 0;
+    v.tlas_top = nullptr; v.tlas_top_n = 0;
     return v;
 }
 
@@ -728,21 +787,25 @@ int scene_mode(const pt_ctx* ctx, LdsScene* ls) {
     auto place = [&](uint32_t bytes) { uint32_t o = off; off += (bytes + 15u) & ~15u; return o; };
     ls->bytes_obj_box = 16u * ctx->n_objects;
     ls->bytes_objects = (uint32_t)sizeof(DObject) * ctx->n_objects;
+    ls->bytes_l2w = (uint32_t)sizeof(Affine) * ctx->n_objects;
     ls->bytes_meshes = (uint32_t)sizeof(DMesh) * ctx->n_meshes;
     ls->bytes_tris = (uint32_t)sizeof(DTri) * ctx->n_tris;
+    ls->bytes_tri_ids = ctx->n_blas_nodes ? (uint32_t)sizeof(uint32_t) * ctx->n_tris : 0u;   // only BLAS leaves look at them
     ls->bytes_attrs = (uint32_t)sizeof(DTriAttr) * ctx->n_tris;
-    ls->bytes_blas = (uint32_t)sizeof(BvhNode) * ctx->n_blas_nodes;
+    ls->bytes_blas = (uint32_t)sizeof(WNode) * ctx->n_blas_nodes;
     ls->bytes_materials = (uint32_t)sizeof(DMaterial) * ctx->n_materials;
     ls->bytes_textures = (uint32_t)sizeof(DTexture) * ctx->n_textures;
-    const uint64_t sum = 5ull * ls->bytes_obj_box + ls->bytes_objects + ls->bytes_meshes + ls->bytes_tris + ls->bytes_attrs +
-                         ls->bytes_blas + ls->bytes_materials + ls->bytes_textures;
+    const uint64_t sum = 5ull * ls->bytes_obj_box + ls->bytes_objects + ls->bytes_l2w + ls->bytes_meshes + ls->bytes_tris + ls->bytes_tri_ids +
+                         ls->bytes_attrs + ls->bytes_blas + ls->bytes_materials + ls->bytes_textures + 64ull;
     if (sum > kLdsSceneMaxBytes) return PT_MODE_LIST;
     ls->off_obj_slab = place(3u * ls->bytes_obj_box);   // 12 floats per object
     ls->off_obj_lo = place(ls->bytes_obj_box);
     ls->off_obj_hi = place(ls->bytes_obj_box);
     ls->off_objects = place(ls->bytes_objects);
+    ls->off_l2w = place(ls->bytes_l2w);
     ls->off_meshes = place(ls->bytes_meshes);
     ls->off_tris = place(ls->bytes_tris);
+    ls->off_tri_ids = place(ls->bytes_tri_ids);
     ls->off_attrs = place(ls->bytes_attrs);
     ls->off_blas = place(ls->bytes_blas);
     ls->off_materials = place(ls->bytes_materials);
@@ -931,21 +994,21 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             const size_t budget = (size_t)ctx->lds_per_cu > lds + 1024 ? (size_t)ctx->lds_per_cu - 1024 - lds : 0;
             uint32_t best = PT_NONE;
             for (uint32_t m = 0; m < ctx->n_meshes; ++m) {
-                if (ctx->h_blas_nodes_base[m] == PT_NONE || ctx->h_meshes[m].tri_count < 2) continue;
-                const size_t nodes = sizeof(BvhNode) * (size_t)(ctx->h_meshes[m].tri_count - 1);
-                if (nodes <= budget && (best == PT_NONE || ctx->h_meshes[m].tri_count > ctx->h_meshes[best].tri_count)) best = m;
+                if (ctx->h_blas_nodes_base[m] == PT_NONE || ctx->h_blas_n_wide[m] == 0) continue;
+                if (lds_blas_bytes(ctx->h_blas_n_wide[m], 0) <= budget && (best == PT_NONE || ctx->h_meshes[m].tri_count > ctx->h_meshes[best].tri_count)) best = m;
             }
             if (best != PT_NONE) {
                 lb.mesh = best;
                 lb.node_base = ctx->h_blas_nodes_base[best];
-                lb.n_nodes = ctx->h_meshes[best].tri_count - 1;
+                lb.n_nodes = ctx->h_blas_n_wide[best];
                 lb.tri_first = ctx->h_meshes[best].tri_first;
-                const size_t nodes = sizeof(BvhNode) * (size_t)lb.n_nodes, tris = sizeof(DTri) * (size_t)ctx->h_meshes[best].tri_count;
-                lb.n_tris = (nodes + tris <= budget) ? ctx->h_meshes[best].tri_count : 0u;
+                lb.n_tris = (lds_blas_bytes(lb.n_nodes, ctx->h_meshes[best].tri_count) <= budget) ? ctx->h_meshes[best].tri_count : 0u;
                 paths_mode = PT_MODE_LIST_LB;
             }
         }
-        const size_t lds_paths = lds + (paths_mode == PT_MODE_LIST_LB ? sizeof(BvhNode) * (size_t)lb.n_nodes + sizeof(DTri) * (size_t)lb.n_tris : 0u);
+        // PT_MODE_TLAS: the top levels of the object tree, the nodes every ray passes, are copied into LDS
+        pp.tlas_top_n = (mode == PT_MODE_TLAS) ? std::min(ctx->tlas_n_wide, ctx->tlas_top_max) : 0u;
+        const size_t lds_paths = lds + (paths_mode == PT_MODE_LIST_LB ? lds_blas_bytes(lb.n_nodes, lb.n_tris) : 0u) + (size_t)pp.tlas_top_n * sizeof(WNode);
         PathsFn fn = ptable[paths_mode][st ? 1 : 0];
         if (lds_paths > 64 * 1024) PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_paths));
         int per_cu = 0;
@@ -1238,23 +1301,38 @@ int pt_debug_check_accel(pt_ctx* ctx, uint32_t* n_errors, uint32_t* tlas_depth, 
         if (!n_errors) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_debug_check_accel: null argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
         hipStream_t s = ctx->stream;
-        PT_HIP(ctx, ctx->t_errors.ensure(sizeof(uint32_t)));
-        PT_HIP(ctx, hipMemsetAsync(ctx->t_errors.p, 0, sizeof(uint32_t), s));
+        // t_errors: [0] violations, [1] primitives found in the leaves of the wide trees
+        PT_HIP(ctx, ctx->t_errors.ensure(2 * sizeof(uint32_t)));
+        PT_HIP(ctx, hipMemsetAsync(ctx->t_errors.p, 0, 2 * sizeof(uint32_t), s));
+        uint64_t want_leaves = 0;
         for (uint32_t m = 0; m < ctx->n_meshes; ++m) {
             if (ctx->h_blas_nodes_base[m] == PT_NONE) continue;
-            const uint32_t ni = ctx->h_meshes[m].tri_count - 1;
-            k_check_bvh<<<div_up(ni, 256), 256, 0, s>>>(ctx->d_blas_nodes.as<BvhNode>() + ctx->h_blas_nodes_base[m],
-                                                        ctx->h_blas_nodes_base[m], ni, ctx->d_tri_lo.as<float4>(),
-                                                        ctx->d_tri_hi.as<float4>(), ctx->h_meshes[m].tri_first,
-                                                        ctx->t_errors.as<uint32_t>());
+            const uint32_t base = ctx->h_blas_nodes_base[m], first = ctx->h_meshes[m].tri_first, ni = ctx->h_meshes[m].tri_count - 1;
+            const BvhNode* bn = ctx->d_blas_bnodes.as<BvhNode>() + base;
+            const uint32_t* order = ctx->d_blas_order.as<uint32_t>() + first;
+            k_check_bvh<<<div_up(ni, 256), 256, 0, s>>>(bn, base, ni, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), first, order, ctx->t_errors.as<uint32_t>());
+            if (const uint32_t nw = ctx->h_blas_n_wide[m]) {
+                k_check_wide<<<div_up(nw, 256), 256, 0, s>>>(ctx->d_blas_nodes.as<WNode>() + base, base, nw, bn, ctx->d_tri_lo.as<float4>(),
+                                                             ctx->d_tri_hi.as<float4>(), first, order, ctx->t_errors.as<uint32_t>());
+                want_leaves += ctx->h_meshes[m].tri_count;
+            }
         }
-        if (ctx->use_tlas && ctx->n_objects > 1)
-            k_check_bvh<<<div_up(ctx->n_objects - 1, 256), 256, 0, s>>>(ctx->d_tlas_nodes.as<BvhNode>(), 0, ctx->n_objects - 1,
-                                                                        ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0,
+        if (ctx->use_tlas && ctx->n_objects > 1) {
+            k_check_bvh<<<div_up(ctx->n_objects - 1, 256), 256, 0, s>>>(ctx->d_tlas_bnodes.as<BvhNode>(), 0, ctx->n_objects - 1,
+                                                                        ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, nullptr,
                                                                         ctx->t_errors.as<uint32_t>());
+            if (ctx->tlas_n_wide) {
+                k_check_wide<<<div_up(ctx->tlas_n_wide, 256), 256, 0, s>>>(ctx->d_tlas_nodes.as<WNode>(), 0, ctx->tlas_n_wide, ctx->d_tlas_bnodes.as<BvhNode>(),
+                                                                           ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, nullptr,
+                                                                           ctx->t_errors.as<uint32_t>());
+                want_leaves += ctx->n_objects;
+            }
+        }
         PT_HIP(ctx, hipGetLastError());
-        PT_HIP(ctx, hipMemcpyAsync(n_errors, ctx->t_errors.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        uint32_t found[2] = {0, 0};
+        PT_HIP(ctx, hipMemcpyAsync(found, ctx->t_errors.p, sizeof found, hipMemcpyDeviceToHost, s));
         PT_HIP(ctx, hipStreamSynchronize(s));
+        *n_errors = found[0] + (found[1] == want_leaves ? 0u : 1u);   // every primitive in exactly one leaf
         if (tlas_depth) *tlas_depth = ctx->use_tlas ? ctx->tlas_depth : 0;
         if (max_blas_depth) *max_blas_depth = ctx->max_blas_depth;
         return PT_OK;

@@ -67,7 +67,7 @@ __global__ void k_build_tris(const WMesh* __restrict__ meshes, const uint32_t* _
 // largest coordinate, and (b) how far local_to_world * world_to_local is from the identity.
 __global__ void k_prep_objects(const WObject* __restrict__ wobj, const uint32_t* __restrict__ tri_base,
                                const DMesh* __restrict__ meshes, uint32_t n, DObject* __restrict__ objects,
-                               float4* __restrict__ box_lo, float4* __restrict__ box_hi) {
+                               Affine* __restrict__ obj_l2w, float4* __restrict__ box_lo, float4* __restrict__ box_hi) {
     uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n) return;
     const WObject* w = &wobj[o];
@@ -75,26 +75,27 @@ __global__ void k_prep_objects(const WObject* __restrict__ wobj, const uint32_t*
     d.w2l.r0 = make_float4(w->w2l[0], w->w2l[4], w->w2l[8], w->w2l[12]);
     d.w2l.r1 = make_float4(w->w2l[1], w->w2l[5], w->w2l[9], w->w2l[13]);
     d.w2l.r2 = make_float4(w->w2l[2], w->w2l[6], w->w2l[10], w->w2l[14]);
-    d.l2w.r0 = make_float4(w->l2w[0], w->l2w[4], w->l2w[8], w->l2w[12]);
-    d.l2w.r1 = make_float4(w->l2w[1], w->l2w[5], w->l2w[9], w->l2w[13]);
-    d.l2w.r2 = make_float4(w->l2w[2], w->l2w[6], w->l2w[10], w->l2w[14]);
+    Affine l2w;
+    l2w.r0 = make_float4(w->l2w[0], w->l2w[4], w->l2w[8], w->l2w[12]);
+    l2w.r1 = make_float4(w->l2w[1], w->l2w[5], w->l2w[9], w->l2w[13]);
+    l2w.r2 = make_float4(w->l2w[2], w->l2w[6], w->l2w[10], w->l2w[14]);
     d.mat = w->mat;
     d.mesh = w->mesh;
     d.tri_base = tri_base[o];
     d.tri_first = meshes[w->mesh].tri_first;
-    d._pad1[0] = d._pad1[1] = d._pad1[2] = d._pad1[3] = 0;
     objects[o] = d;
+    obj_l2w[o] = l2w;
 
     DMesh me = meshes[w->mesh];
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int k = 0; k < 8; ++k) {
         v3 c = V3((k & 1) ? me.bmax[0] : me.bmin[0], (k & 2) ? me.bmax[1] : me.bmin[1], (k & 4) ? me.bmax[2] : me.bmin[2]);
-        v3 p = xform_point(d.l2w, c);
+        v3 p = xform_point(l2w, c);
         lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
         hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
     }
     // residual of l2w * w2l against the identity (3x4 affine parts)
-    const float4 L[3] = {d.l2w.r0, d.l2w.r1, d.l2w.r2};
+    const float4 L[3] = {l2w.r0, l2w.r1, l2w.r2};
     const float4 Wm[3] = {d.w2l.r0, d.w2l.r1, d.w2l.r2};
     float resid = 0.0f;
     for (int i = 0; i < 3; ++i) {
@@ -278,8 +279,9 @@ PT_DEV int lbvh_delta(const uint32_t* __restrict__ keys, int n, int i, int j) {
     if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
     return __clz(a ^ b);
 }
+// ranges (may be null): for internal node i the sorted positions [x, y] of the keys below it.
 __global__ void k_karras(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ parent_internal,
-                         uint32_t* __restrict__ parent_leaf) {
+                         uint32_t* __restrict__ parent_leaf, uint2* __restrict__ ranges) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int ni = (int)n;
     if (i >= ni - 1) return;
@@ -300,6 +302,7 @@ __global__ void k_karras(const uint32_t* __restrict__ keys, uint32_t n, uint32_t
     } while (t > 1);
     int gamma = i + s * d + min(d, 0);
     int lo = min(i, j), hi = max(i, j);
+    if (ranges) ranges[i] = make_uint2((uint32_t)lo, (uint32_t)hi);
     // the left child covers [lo, gamma], the right one [gamma+1, hi]; a one-key range is a leaf.
     // parent link: bit 31 = "I am the right child"
     if (lo == gamma) parent_leaf[gamma] = (uint32_t)i; else parent_internal[gamma] = (uint32_t)i;
@@ -311,15 +314,17 @@ __global__ void k_karras(const uint32_t* __restrict__ keys, uint32_t n, uint32_t
 // handed between workgroups (possibly on different XCDs, whose L2s are not coherent) with an
 // agent-scope release before the counter increment and an agent-scope acquire after it.
 // out_info[0] = longest root-to-leaf path in internal nodes.
+// leaf_is_pos: a leaf is referenced by its position in the sorted order (BLAS: the triangle records are stored in that
+// order) instead of by the primitive's own number (TLAS: the object).
 __global__ void k_fit(const float4* __restrict__ box_lo, const float4* __restrict__ box_hi, uint32_t first,
                       const uint32_t* __restrict__ sorted_prim, uint32_t n, const uint32_t* __restrict__ parent_internal,
                       const uint32_t* __restrict__ parent_leaf, uint32_t* __restrict__ arrive, BvhNode* __restrict__ nodes,
-                      uint32_t node_base, uint32_t* __restrict__ out_info) {
+                      uint32_t node_base, uint32_t* __restrict__ out_info, uint32_t leaf_is_pos) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t prim = sorted_prim[k];
     float4 lo = box_lo[first + prim], hi = box_hi[first + prim];
-    uint32_t ref = PT_LEAF_BIT | prim;
+    uint32_t ref = PT_LEAF_BIT | (leaf_is_pos ? k : prim);
     uint32_t depth = 0;
     uint32_t link = parent_leaf[k];
     while (true) {
@@ -354,9 +359,10 @@ __global__ void k_fit(const float4* __restrict__ box_lo, const float4* __restric
 
 // Checks every node of a built tree: each stored child box must contain what is below it.
 // errors[0] counts violations. (Debug / test aid.)
+// sorted_prim (may be null): leaf references are positions in this order instead of primitive numbers.
 __global__ void k_check_bvh(const BvhNode* __restrict__ nodes, uint32_t node_base, uint32_t n_internal,
                             const float4* __restrict__ box_lo, const float4* __restrict__ box_hi, uint32_t first,
-                            uint32_t* __restrict__ errors) {
+                            const uint32_t* __restrict__ sorted_prim, uint32_t* __restrict__ errors) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_internal) return;
     const BvhNode N = nodes[i];
@@ -365,8 +371,9 @@ __global__ void k_check_bvh(const BvhNode* __restrict__ nodes, uint32_t node_bas
         uint32_t ref = __float_as_uint(lo.w);
         float4 clo, chi;
         if (ref & PT_LEAF_BIT) {
-            clo = box_lo[first + (ref & ~PT_LEAF_BIT)];
-            chi = box_hi[first + (ref & ~PT_LEAF_BIT)];
+            const uint32_t prim = sorted_prim ? sorted_prim[ref & ~PT_LEAF_BIT] : (ref & ~PT_LEAF_BIT);
+            clo = box_lo[first + prim];
+            chi = box_hi[first + prim];
         } else {
             uint32_t c = ref - node_base;
             if (c >= n_internal) { atomicAdd(&errors[0], 1u); continue; }
@@ -377,4 +384,216 @@ __global__ void k_check_bvh(const BvhNode* __restrict__ nodes, uint32_t node_bas
         bool ok = lo.x <= clo.x && lo.y <= clo.y && lo.z <= clo.z && hi.x >= chi.x && hi.y >= chi.y && hi.z >= chi.z;
         if (!ok) atomicAdd(&errors[0], 1u);
     }
+}
+
+// ---- triangle records of a mesh with a BLAS, in the order of the tree's leaves ---------------------------------------
+__global__ void k_permute_tris(const DTri* __restrict__ tris_in, const uint32_t* __restrict__ sorted_prim, uint32_t n,
+                               DTri* __restrict__ tris_out, uint32_t* __restrict__ tri_ids) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t prim = sorted_prim[k];
+    tris_out[k] = tris_in[prim];
+    tri_ids[k] = prim;
+}
+__global__ void k_iota(uint32_t* __restrict__ out, uint32_t n) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = k;
+}
+
+// ---- 4-wide tree from the binary one --------------------------------------------------------------------------------
+// One workgroup walks the binary tree breadth first. A wide node starts from a binary node's two children and, while it
+// has a free slot, replaces the child with the largest surface area that can still be opened by that child's two
+// children (a greedy surface-area collapse). In a BLAS a subtree of at most `max_leaf` triangles is not opened: it
+// becomes one leaf (the triangles below a binary node are consecutive in the sorted order, `ranges`). The nodes of one
+// level get consecutive numbers after those of the level above, a node's own children consecutive ones.
+//   work[]  : per wide node, x = the binary node it starts from, y = stack entries a walk holds when it arrives there
+//   info[0] = number of wide nodes, [1] = levels, [2] = reference of the root, [3] = stack entries a walk can need
+// Conservative boxes: child boxes are grown by 2^-20 of the node's largest coordinate before they are put on the grid
+// (the ray side evaluates origin + q * step as two fused operations, not one), and every stored corner is decoded with
+// fmaf(q, step, origin) and moved outward until it encloses the real one.
+struct CollapseSlot {
+    uint32_t ref;
+    float lo[3], hi[3];
+};
+PT_DEV float slot_area(const CollapseSlot& c) {
+    const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+__global__ __launch_bounds__(1024) void k_collapse(const BvhNode* __restrict__ bnodes, uint32_t bnode_base, uint32_t n_prims,
+                                                   const uint2* __restrict__ ranges, uint32_t max_leaf,
+                                                   WNode* __restrict__ wnodes, uint32_t wnode_base, uint2* __restrict__ work,
+                                                   uint32_t* __restrict__ info) {
+    __shared__ uint32_t s_begin, s_end, s_next, s_need, s_levels;
+    const uint32_t tid = threadIdx.x;
+    if (n_prims < 2u || (ranges && n_prims <= max_leaf)) {   // no node at all: the root is a leaf
+        if (tid == 0) {
+            info[0] = 0; info[1] = 0; info[3] = 0;
+            info[2] = ranges ? (PT_LEAF_BIT | ((n_prims - 1u) << PT_WLEAF_COUNT_SHIFT)) : (PT_LEAF_BIT | 0u);
+        }
+        return;
+    }
+    if (tid == 0) {
+        work[0] = make_uint2(0u, 0u);
+        s_begin = 0; s_end = 1; s_next = 1; s_need = 0; s_levels = 0;
+    }
+    __syncthreads();
+    auto count_below = [&](uint32_t ref) -> uint32_t {   // primitives below a binary child reference
+        if (ref & PT_LEAF_BIT) return 1u;
+        if (!ranges) return 0xFFFFFFFFu;
+        const uint2 r = ranges[ref - bnode_base];
+        return r.y - r.x + 1u;
+    };
+    for (;;) {
+        const uint32_t begin = s_begin, end = s_end;
+        if (begin == end) break;
+        for (uint32_t w = begin + tid; w < end; w += blockDim.x) {
+            const uint2 item = work[w];
+            CollapseSlot sl[4];
+            int n = 2;
+            {
+                const BvhNode B = bnodes[item.x];
+                sl[0].ref = __float_as_uint(B.lo_l.w); sl[0].lo[0] = B.lo_l.x; sl[0].lo[1] = B.lo_l.y; sl[0].lo[2] = B.lo_l.z;
+                sl[0].hi[0] = B.hi_l.x; sl[0].hi[1] = B.hi_l.y; sl[0].hi[2] = B.hi_l.z;
+                sl[1].ref = __float_as_uint(B.lo_r.w); sl[1].lo[0] = B.lo_r.x; sl[1].lo[1] = B.lo_r.y; sl[1].lo[2] = B.lo_r.z;
+                sl[1].hi[0] = B.hi_r.x; sl[1].hi[1] = B.hi_r.y; sl[1].hi[2] = B.hi_r.z;
+            }
+            while (n < 4) {
+                int best = -1;
+                float best_area = -1.0f;
+                for (int j = 0; j < n; ++j) {
+                    if (sl[j].ref & PT_LEAF_BIT) continue;
+                    if (ranges && count_below(sl[j].ref) <= max_leaf) continue;
+                    const float a = slot_area(sl[j]);
+                    if (!(a <= best_area)) { best_area = a; best = j; }   // (a NaN area is opened too)
+                }
+                if (best < 0) break;
+                const BvhNode B = bnodes[sl[best].ref - bnode_base];
+                sl[best].ref = __float_as_uint(B.lo_l.w); sl[best].lo[0] = B.lo_l.x; sl[best].lo[1] = B.lo_l.y; sl[best].lo[2] = B.lo_l.z;
+                sl[best].hi[0] = B.hi_l.x; sl[best].hi[1] = B.hi_l.y; sl[best].hi[2] = B.hi_l.z;
+                sl[n].ref = __float_as_uint(B.lo_r.w); sl[n].lo[0] = B.lo_r.x; sl[n].lo[1] = B.lo_r.y; sl[n].lo[2] = B.lo_r.z;
+                sl[n].hi[0] = B.hi_r.x; sl[n].hi[1] = B.hi_r.y; sl[n].hi[2] = B.hi_r.z;
+                ++n;
+            }
+            // children: leaves keep / get their leaf reference, the others become wide nodes of the next level
+            uint32_t n_inner = 0;
+            for (int j = 0; j < n; ++j)
+                if (!(sl[j].ref & PT_LEAF_BIT) && !(ranges && count_below(sl[j].ref) <= max_leaf)) ++n_inner;
+            const uint32_t base = n_inner ? atomicAdd(&s_next, n_inner) : 0u;
+            const uint32_t held = item.y + (uint32_t)n - 1u;   // entries on the stack while a walk is below this node
+            atomicMax(&s_need, held);
+            WNode N;
+            uint32_t r = 0;
+            for (int j = 0; j < 4; ++j) {
+                if (j >= n) { N.child[j] = PT_NONE; continue; }
+                const uint32_t ref = sl[j].ref;
+                if (ref & PT_LEAF_BIT) {
+                    N.child[j] = ref;   // TLAS: the object; BLAS: one triangle at this position (count - 1 = 0)
+                } else if (ranges && count_below(ref) <= max_leaf) {
+                    const uint2 rg = ranges[ref - bnode_base];
+                    N.child[j] = PT_LEAF_BIT | ((rg.y - rg.x) << PT_WLEAF_COUNT_SHIFT) | rg.x;
+                } else {
+                    work[base + r] = make_uint2(ref - bnode_base, held);
+                    N.child[j] = wnode_base + base + r;
+                    ++r;
+                }
+            }
+            // the grid
+            float big = 0.0f;
+            for (int j = 0; j < n; ++j)
+                for (int a = 0; a < 3; ++a) big = fmaxf(big, fmaxf(fabsf(sl[j].lo[a]), fabsf(sl[j].hi[a])));
+            const float pad = fminf(big, 1.7e38f) * 0x1p-20f;
+            uint32_t exps = 0;
+            for (int a = 0; a < 3; ++a) {
+                float mn = 3.0e38f, mx = -3.0e38f;
+                for (int j = 0; j < n; ++j) { mn = fminf(mn, sl[j].lo[a] - pad); mx = fmaxf(mx, sl[j].hi[a] + pad); }
+                mn = fmaxf(mn, -1.7e38f);   // ("unbounded" boxes of objects with non-finite transforms: keep the extent finite)
+                mx = fminf(mx, 1.7e38f);
+                const float o = mn;
+                const float t = (mx - o) * (1.0f / 253.0f);
+                int e = -100;
+                if (t > 0.0f) { (void)frexpf(t, &e); }   // t = m * 2^e, m in [0.5, 1): 2^e >= t
+                e = min(max(e, -100), 126);
+                const float step = ldexpf(1.0f, e), inv_step = ldexpf(1.0f, -e);
+                uint32_t wlo = 0, whi = 0;
+                for (int j = 0; j < 4; ++j) {
+                    int ql = 255, qh = 0;   // empty slot: inverted
+                    if (j < n) {
+                        const float lo = fmaxf(sl[j].lo[a] - pad, -1.7e38f), hi = fminf(sl[j].hi[a] + pad, 1.7e38f);
+                        ql = (int)fminf(fmaxf(floorf((lo - o) * inv_step), 0.0f), 255.0f);
+                        while (ql > 0 && fmaf((float)ql, step, o) > lo) --ql;
+                        qh = (int)fminf(fmaxf(ceilf((hi - o) * inv_step), 0.0f), 255.0f);
+                        while (qh < 255 && fmaf((float)qh, step, o) < hi) ++qh;
+                    }
+                    wlo |= (uint32_t)ql << (8 * j);
+                    whi |= (uint32_t)qh << (8 * j);
+                }
+                N.origin[a] = o;
+                N.qlo[a] = wlo;
+                N.qhi[a] = whi;
+                exps |= (uint32_t)(e + 127) << (8 * a);
+            }
+            N.exps = exps;
+            N._pad[0] = item.x;   // (build bookkeeping: the binary node this one started from)
+            N._pad[1] = held;
+            wnodes[w] = N;
+        }
+        __syncthreads();
+        if (tid == 0) { s_begin = end; s_end = s_next; s_levels++; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        info[0] = s_next;
+        info[1] = s_levels;
+        info[2] = wnode_base;
+        info[3] = s_need;
+    }
+}
+
+// Checks a wide tree: every child box, decoded the way the comment of WNode says, must enclose what lies below it (the
+// primitives' boxes for a leaf; for a node, the box of the binary subtree it was made from, which k_check_bvh in turn
+// checks against the primitives), and the leaves must hold every primitive
+// exactly once (counted into errors[1], compared with the number of primitives by the caller). errors[0] counts
+// violations. prim_of_pos (BLAS): the primitive stored at a sorted position; null (TLAS): leaves name primitives directly.
+PT_DEV void wnode_child_box(const WNode& N, int j, float lo[3], float hi[3]) {
+    for (int a = 0; a < 3; ++a) {
+        const float step = __uint_as_float(((N.exps >> (8 * a)) & 0xFFu) << 23);
+        lo[a] = fmaf((float)((N.qlo[a] >> (8 * j)) & 0xFFu), step, N.origin[a]);
+        hi[a] = fmaf((float)((N.qhi[a] >> (8 * j)) & 0xFFu), step, N.origin[a]);
+    }
+}
+__global__ void k_check_wide(const WNode* __restrict__ wnodes, uint32_t wnode_base, uint32_t n_nodes, const BvhNode* __restrict__ bnodes,
+                             const float4* __restrict__ box_lo, const float4* __restrict__ box_hi, uint32_t first,
+                             const uint32_t* __restrict__ prim_of_pos, uint32_t* __restrict__ errors) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const WNode N = wnodes[i];
+    uint32_t leaves = 0, bad = 0;
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t ref = N.child[j];
+        if (ref == PT_NONE) continue;
+        float lo[3], hi[3];
+        wnode_child_box(N, j, lo, hi);
+        if (ref & PT_LEAF_BIT) {
+            const uint32_t pos = prim_of_pos ? (ref & PT_WLEAF_POS_MASK) : (ref & ~PT_LEAF_BIT);
+            const uint32_t cnt = prim_of_pos ? (((ref & ~PT_LEAF_BIT) >> PT_WLEAF_COUNT_SHIFT) + 1u) : 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t prim = prim_of_pos ? prim_of_pos[pos + k] : pos;
+                const float4 a = box_lo[first + prim], b = box_hi[first + prim];
+                if (!(lo[0] <= fmaxf(a.x, -1.7e38f) && lo[1] <= fmaxf(a.y, -1.7e38f) && lo[2] <= fmaxf(a.z, -1.7e38f) &&
+                      hi[0] >= fminf(b.x, 1.7e38f) && hi[1] >= fminf(b.y, 1.7e38f) && hi[2] >= fminf(b.z, 1.7e38f))) ++bad;
+            }
+            leaves += cnt;
+        } else {
+            const uint32_t c = ref - wnode_base;
+            if (c >= n_nodes || c <= i) { ++bad; continue; }   // (breadth-first numbering: children come later)
+            const BvhNode B = bnodes[wnodes[c]._pad[0]];
+            const float clo[3] = {fminf(B.lo_l.x, B.lo_r.x), fminf(B.lo_l.y, B.lo_r.y), fminf(B.lo_l.z, B.lo_r.z)};
+            const float chi[3] = {fmaxf(B.hi_l.x, B.hi_r.x), fmaxf(B.hi_l.y, B.hi_r.y), fmaxf(B.hi_l.z, B.hi_r.z)};
+            // (boxes beyond +-1.7e38 are stored clipped to that: objects whose transform is not finite)
+            if (!(lo[0] <= fmaxf(clo[0], -1.7e38f) && lo[1] <= fmaxf(clo[1], -1.7e38f) && lo[2] <= fmaxf(clo[2], -1.7e38f) &&
+                  hi[0] >= fminf(chi[0], 1.7e38f) && hi[1] >= fminf(chi[1], 1.7e38f) && hi[2] >= fminf(chi[2], 1.7e38f))) ++bad;
+        }
+    }
+    if (bad) atomicAdd(&errors[0], bad);
+    if (leaves) atomicAdd(&errors[1], leaves);
 }

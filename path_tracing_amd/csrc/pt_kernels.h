@@ -63,14 +63,15 @@ struct PathParams {
     uint32_t n_sweeps;      // the samples of a pixel are run in this many consecutive slices (1..PT_MAX_SWEEPS)
     uint32_t sweep_end[8];  // slice j runs samples [sweep_end[j-1], sweep_end[j]); sweep_end[n_sweeps-1] == samples
     uint32_t split_chunks;  // 1: the most expensive chunks are handed out in parts (ChunkOrderInfo::n_split)
+    uint32_t tlas_top_n;    // PT_MODE_TLAS: nodes of the TLAS (its top levels) every workgroup copies into LDS
 };
 #define PT_MAX_SWEEPS 8
 
 // Where each scene array sits in the LDS copy (byte offsets from the start of the staged region, multiples of 16)
 // and how many bytes it has. Small scenes only: see lds_scene_layout() on the host side.
 struct LdsScene {
-    uint32_t off_obj_slab, off_obj_lo, off_obj_hi, off_objects, off_meshes, off_tris, off_attrs, off_blas, off_materials, off_textures;
-    uint32_t bytes_obj_box, bytes_objects, bytes_meshes, bytes_tris, bytes_attrs, bytes_blas, bytes_materials, bytes_textures;
+    uint32_t off_obj_slab, off_obj_lo, off_obj_hi, off_objects, off_l2w, off_meshes, off_tris, off_tri_ids, off_attrs, off_blas, off_materials, off_textures;
+    uint32_t bytes_obj_box, bytes_objects, bytes_l2w, bytes_meshes, bytes_tris, bytes_tri_ids, bytes_attrs, bytes_blas, bytes_materials, bytes_textures;
     uint32_t total_bytes;
 };
 
@@ -86,8 +87,10 @@ PT_DEV void stage_scene_in_lds(SceneView& sc, const LdsScene& ls, uint32_t* lds)
     lds_copy16(lds + ls.off_obj_lo / 4, sc.obj_lo, ls.bytes_obj_box);
     lds_copy16(lds + ls.off_obj_hi / 4, sc.obj_hi, ls.bytes_obj_box);
     lds_copy16(lds + ls.off_objects / 4, sc.objects, ls.bytes_objects);
+    lds_copy16(lds + ls.off_l2w / 4, sc.obj_l2w, ls.bytes_l2w);
     lds_copy16(lds + ls.off_meshes / 4, sc.meshes, ls.bytes_meshes);
     lds_copy16(lds + ls.off_tris / 4, sc.tris, ls.bytes_tris);
+    for (uint32_t i = threadIdx.x; i < ls.bytes_tri_ids / 4u; i += blockDim.x) lds[ls.off_tri_ids / 4 + i] = sc.tri_ids[i];
     lds_copy16(lds + ls.off_attrs / 4, sc.tri_attrs, ls.bytes_attrs);
     lds_copy16(lds + ls.off_blas / 4, sc.blas_nodes, ls.bytes_blas);
     lds_copy16(lds + ls.off_materials / 4, sc.materials, ls.bytes_materials);
@@ -107,10 +110,12 @@ PT_DEV void stage_scene_in_lds(SceneView& sc, const LdsScene& ls, uint32_t* lds)
     sc.obj_lo = reinterpret_cast<const float4*>(lds + ls.off_obj_lo / 4);
     sc.obj_hi = reinterpret_cast<const float4*>(lds + ls.off_obj_hi / 4);
     sc.objects = reinterpret_cast<const DObject*>(lds + ls.off_objects / 4);
+    sc.obj_l2w = reinterpret_cast<const Affine*>(lds + ls.off_l2w / 4);
     sc.meshes = reinterpret_cast<const DMesh*>(lds + ls.off_meshes / 4);
     sc.tris = reinterpret_cast<const DTri*>(lds + ls.off_tris / 4);
+    sc.tri_ids = lds + ls.off_tri_ids / 4;
     sc.tri_attrs = reinterpret_cast<const DTriAttr*>(lds + ls.off_attrs / 4);
-    sc.blas_nodes = reinterpret_cast<const BvhNode*>(lds + ls.off_blas / 4);
+    sc.blas_nodes = reinterpret_cast<const WNode*>(lds + ls.off_blas / 4);
     sc.materials = reinterpret_cast<const DMaterial*>(lds + ls.off_materials / 4);
     sc.textures = reinterpret_cast<const DTexture*>(lds + ls.off_textures / 4);
 }
@@ -119,15 +124,31 @@ PT_DEV void stage_scene_in_lds(SceneView& sc, const LdsScene& ls, uint32_t* lds)
 struct LdsBlas {
     uint32_t mesh, node_base, n_nodes, tri_first, n_tris;   // n_tris == 0: triangles stay in global memory
 };
+__host__ __device__ constexpr uint32_t lds_blas_bytes(uint32_t n_nodes, uint32_t n_tris) {
+    return n_nodes * (uint32_t)sizeof(WNode) + n_tris * (uint32_t)(sizeof(DTri) + sizeof(uint32_t));
+}
 PT_DEV void stage_blas_in_lds(SceneView& sc, const LdsBlas& lb, uint32_t* lds) {
-    lds_copy16(lds, sc.blas_nodes + lb.node_base, lb.n_nodes * (uint32_t)sizeof(BvhNode));
-    uint32_t* tris = lds + lb.n_nodes * (uint32_t)(sizeof(BvhNode) / 4);
-    if (lb.n_tris) lds_copy16(tris, sc.tris + lb.tri_first, lb.n_tris * (uint32_t)sizeof(DTri));
+    lds_copy16(lds, sc.blas_nodes + lb.node_base, lb.n_nodes * (uint32_t)sizeof(WNode));
+    uint32_t* tris = lds + lb.n_nodes * (uint32_t)(sizeof(WNode) / 4);
+    uint32_t* ids = tris + lb.n_tris * (uint32_t)(sizeof(DTri) / 4);
+    if (lb.n_tris) {
+        lds_copy16(tris, sc.tris + lb.tri_first, lb.n_tris * (uint32_t)sizeof(DTri));
+        for (uint32_t i = threadIdx.x; i < lb.n_tris; i += blockDim.x) ids[i] = sc.tri_ids[lb.tri_first + i];
+    }
     __syncthreads();
-    sc.lb_nodes = reinterpret_cast<const BvhNode*>(lds);
+    sc.lb_nodes = reinterpret_cast<const WNode*>(lds);
     sc.lb_tris = lb.n_tris ? reinterpret_cast<const DTri*>(tris) : nullptr;
+    sc.lb_tri_ids = lb.n_tris ? ids : nullptr;
     sc.lb_mesh = lb.mesh;
     sc.lb_node_base = lb.node_base;
+}
+// The top levels of the TLAS (its first n nodes: the tree is numbered breadth first) copied into LDS.
+PT_DEV void stage_tlas_top_in_lds(SceneView& sc, uint32_t n, uint32_t* lds) {
+    if (n == 0u) return;
+    lds_copy16(lds, sc.tlas_nodes, n * (uint32_t)sizeof(WNode));
+    __syncthreads();
+    sc.tlas_top = reinterpret_cast<const WNode*>(lds);
+    sc.tlas_top_n = n;
 }
 
 PT_DEV uint32_t wave_sum_u32(uint32_t v) {
@@ -406,6 +427,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     const uint32_t lds_fixed = 4 * (stack_depth + SLOTS) * 64 + 4 * PT_SCHED_WORDS;
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + lds_fixed);
     if (MODE == PT_MODE_LIST_LB) stage_blas_in_lds(sc, lb, s_mem + lds_fixed);
+    if (MODE == PT_MODE_TLAS) stage_tlas_top_in_lds(sc, pp.tlas_top_n, s_mem + lds_fixed);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     LdsStack stk;
     stk.base = &s_mem[wave * stack_depth * 64 + lane];
@@ -439,7 +461,7 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0);
     HitInfo h;
     h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
-    // PT_MODE_TLAS: a lane's TLAS walk survives the rounds of the loop below (see bvh_walk_resume)
+    // PT_MODE_TLAS: a lane's TLAS walk survives the rounds of the loop below (see wide_walk_resume)
     WalkState ws = {PT_WALK_DONE, 0};
     Best wb;
     wb.t = PT_T_MAX; wb.obj = PT_NONE; wb.tri = PT_NONE; wb.u = 0.0f; wb.v = 0.0f;
@@ -769,9 +791,9 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
             // four lanes in five idle.
             if (__any(st == PT_ST_TRACE)) {
                 const bool tracing = st == PT_ST_TRACE;
-                const SlabRay sr = world_slab_ray(rpos, rdir);
-                bvh_walk_resume<STATS, PT_BURST_TLAS>(sc.tlas_nodes, sr, wb.t, stk, ws, pp.walk_quota, cnt,
-                                                      [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, rpos, rdir, wb, stk, sp, cnt); });
+                const WideRay wr = make_wide_ray(world_slab_ray(rpos, rdir));
+                wide_walk_resume<STATS, PT_BURST_TLAS>([&](uint32_t r) { return tlas_node_at(sc, r); }, wr, wb.t, stk, ws, pp.walk_quota, cnt,
+                                                       [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, rpos, rdir, wb, stk, sp, cnt); });
                 if (tracing && ws.node == PT_WALK_DONE) {
                     nrays++;
                     lane_rays++;

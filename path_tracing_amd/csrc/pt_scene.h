@@ -4,17 +4,18 @@
 
 #include "pt_math.h"
 
-// One instance. 128 B, read as 8 x dwordx4 (scalar loads when the object index is wave-uniform).
+// One instance, the part every ray-object test reads. 64 B = 4 x dwordx4 (scalar loads when the object index is
+// wave-uniform). local_to_world, needed once per ray for the winner only, is kept in an array of its own (obj_l2w), so
+// that the records a traversal touches take half the cache.
 struct DObject {
     Affine w2l;          // world_to_local rows (reference src/query.wgsl:73-74)
-    Affine l2w;          // local_to_world rows (reference src/query.wgsl:118-119)
-    uint32_t mat;
     uint32_t mesh;
-    uint32_t tri_base;   // flat triangle id of this object's triangle 0 (order of the reference's double loop)
     uint32_t tri_first;  // == meshes[mesh].tri_first, so that the hit record needs no trip through the mesh record
-    uint32_t _pad1[4];
+    uint32_t mat;
+    uint32_t tri_base;   // flat triangle id of this object's triangle 0 (order of the reference's double loop)
 };
-static_assert(sizeof(DObject) == 128, "DObject");
+static_assert(sizeof(DObject) == 64, "DObject");
+static_assert(sizeof(Affine) == 48, "Affine");   // obj_l2w[]: local_to_world rows (reference src/query.wgsl:118-119)
 
 // One mesh. 48 B.
 struct DMesh {
@@ -22,8 +23,8 @@ struct DMesh {
     uint32_t tri_first;   // first record of this mesh in tris[] / tri_attrs[]
     float bmax[3];
     uint32_t tri_count;
-    uint32_t blas_root;   // node index into blas_nodes[], a leaf reference (PT_LEAF_BIT|tri), or PT_NONE (= loop over all triangles)
-    uint32_t blas_depth;  // longest root-to-leaf path, in nodes
+    uint32_t blas_root;   // node index into blas_nodes[], a leaf reference (WNode::child), or PT_NONE (= loop over all triangles)
+    uint32_t blas_need;   // traversal stack entries a walk of this BLAS can need
     float max_abs;        // largest |coordinate| of the mesh AABB
     uint32_t _pad;
 };
@@ -48,8 +49,9 @@ struct DTriAttr {
 };
 static_assert(sizeof(DTriAttr) == 64, "DTriAttr");
 
-// Binary BVH node holding the boxes of both children. 64 B = 4 x dwordx4.
-// A child reference with PT_LEAF_BIT set is a primitive (triangle of the mesh for a BLAS, object for the TLAS).
+// Binary BVH node holding the boxes of both children. 64 B = 4 x dwordx4. What the LBVH build produces; the rays walk
+// the 4-wide trees (WNode) made from these.
+// A child reference with PT_LEAF_BIT set is a primitive (position in the sorted order for a BLAS, object for the TLAS).
 #define PT_LEAF_BIT 0x80000000u
 struct BvhNode {
     float4 lo_l;  // left  min.xyz, w = bits of the left child reference
@@ -58,6 +60,29 @@ struct BvhNode {
     float4 hi_r;  // right max.xyz, w = bits of the right subtree's depth
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
+
+// Node of the 4-wide trees the rays walk (TLAS over objects, BLAS over a mesh's triangles). 64 B = 4 x dwordx4.
+// The boxes of the (up to) four children are stored as 8-bit offsets on a per-node grid: child k covers, on axis a,
+//   [ origin[a] + qlo[a].byte(k) * 2^(e[a] - 127),  origin[a] + qhi[a].byte(k) * 2^(e[a] - 127) ]
+// which encloses the child's real box (lower corner rounded down, upper corner rounded up, checked at build time with
+// the very expression above). A slot without a child holds PT_NONE and an inverted box.
+// Child references: an index into the node array (a TLAS or BLAS of its own numbering), or, with PT_LEAF_BIT set, a leaf:
+//   TLAS: PT_LEAF_BIT | object index
+//   BLAS: PT_LEAF_BIT | (count - 1) << 29 | position: `count` (1..4) triangles from `position` on in the mesh's
+//         triangle records, which are stored in the order of the tree's leaves (tri_ids[] gives their mesh numbering).
+// Nodes are numbered breadth first: the top levels of a tree are a prefix of its array.
+#define PT_WLEAF_COUNT_SHIFT 29
+#define PT_WLEAF_POS_MASK 0x1FFFFFFFu
+#define PT_WIDE_MAX_LEAF 4u
+struct WNode {
+    float origin[3];
+    uint32_t exps;       // e[0] | e[1] << 8 | e[2] << 16 (biased exponents of the grid steps)
+    uint32_t child[4];
+    uint32_t qlo[3];     // per axis: byte k = lower corner of child k
+    uint32_t qhi[3];     // per axis: byte k = upper corner of child k
+    uint32_t _pad[2];
+};
+static_assert(sizeof(WNode) == 64, "WNode");
 
 struct DMaterial {  // == PtMaterial (reference src/raytrace.wgsl:29-39)
     float albedo[3];
@@ -80,11 +105,13 @@ struct DTexture {  // == PtTexture (reference src/raytrace.wgsl:41-46)
 // Everything a trace kernel reads, passed by value as one kernel argument.
 struct SceneView {
     const DObject* __restrict__ objects;
+    const Affine* __restrict__ obj_l2w;
     const DMesh* __restrict__ meshes;
-    const DTri* __restrict__ tris;
+    const DTri* __restrict__ tris;         // meshes with a BLAS: in the order of the tree's leaves
+    const uint32_t* __restrict__ tri_ids;  // ... and the triangle's number in its mesh for each of those records
     const DTriAttr* __restrict__ tri_attrs;
-    const BvhNode* __restrict__ blas_nodes;
-    const BvhNode* __restrict__ tlas_nodes;
+    const WNode* __restrict__ blas_nodes;
+    const WNode* __restrict__ tlas_nodes;
     const float4* __restrict__ obj_lo;   // padded world box of every object (what the TLAS is built from)
     const float4* __restrict__ obj_hi;
     const DMaterial* __restrict__ materials;
@@ -101,9 +128,13 @@ struct SceneView {
     // PT_MODE_LDS only: the padded world boxes staged in LDS as 12 floats per object, (lo, hi, lo, 0) per axis, so that a
     // lane reads (near, far) of an axis as two consecutive words from an address chosen by the sign of its ray direction
     const float* obj_slab;
-    const BvhNode* lb_nodes;  // its nodes; a node reference r of that mesh is lb_nodes[r - lb_node_base]
+    const WNode* lb_nodes;    // its nodes; a node reference r of that mesh is lb_nodes[r - lb_node_base]
     const DTri* lb_tris;      // its triangle records (null: they stay in global memory)
+    const uint32_t* lb_tri_ids;
     uint32_t lb_mesh, lb_node_base;
+    // PT_MODE_TLAS: the first tlas_top_n nodes of the TLAS (its top levels) staged in LDS by the kernel
+    const WNode* tlas_top;
+    uint32_t tlas_top_n;
 };
 
 // The kernels take the scene arrays as separate `const T* __restrict__` parameters (PT_SCENE_PARAMS) and rebuild a
@@ -113,23 +144,26 @@ struct SceneScalars {
     uint32_t n_objects, n_texture_data, tlas_root, cull_boxes, tie_lowest;
 };
 #define PT_SCENE_PARAMS                                                                                                \
-    const DObject *__restrict__ p_objects, const DMesh *__restrict__ p_meshes, const DTri *__restrict__ p_tris,         \
-        const DTriAttr *__restrict__ p_attrs, const BvhNode *__restrict__ p_blas, const BvhNode *__restrict__ p_tlas,   \
+    const DObject *__restrict__ p_objects, const Affine *__restrict__ p_l2w, const DMesh *__restrict__ p_meshes,        \
+        const DTri *__restrict__ p_tris, const uint32_t *__restrict__ p_tri_ids, const DTriAttr *__restrict__ p_attrs,  \
+        const WNode *__restrict__ p_blas, const WNode *__restrict__ p_tlas,                                             \
         const float4 *__restrict__ p_obj_lo, const float4 *__restrict__ p_obj_hi,                                       \
         const DMaterial *__restrict__ p_materials, const DTexture *__restrict__ p_textures,                             \
         const float *__restrict__ p_texdata, SceneScalars ss
 #define PT_SCENE_ARGS(v)                                                                                               \
-    (v).objects, (v).meshes, (v).tris, (v).tri_attrs, (v).blas_nodes, (v).tlas_nodes, (v).obj_lo, (v).obj_hi,           \
-        (v).materials, (v).textures, (v).texture_data,                                                                  \
+    (v).objects, (v).obj_l2w, (v).meshes, (v).tris, (v).tri_ids, (v).tri_attrs, (v).blas_nodes, (v).tlas_nodes,         \
+        (v).obj_lo, (v).obj_hi, (v).materials, (v).textures, (v).texture_data,                                          \
         SceneScalars { (v).n_objects, (v).n_texture_data, (v).tlas_root, (v).cull_boxes, (v).tie_lowest }
 #define PT_SCENE_VIEW_FROM_PARAMS()                                                                                    \
     SceneView sc;                                                                                                       \
-    sc.objects = p_objects; sc.meshes = p_meshes; sc.tris = p_tris; sc.tri_attrs = p_attrs; sc.blas_nodes = p_blas;     \
+    sc.objects = p_objects; sc.obj_l2w = p_l2w; sc.meshes = p_meshes; sc.tris = p_tris; sc.tri_ids = p_tri_ids;         \
+    sc.tri_attrs = p_attrs; sc.blas_nodes = p_blas;                                                                     \
     sc.tlas_nodes = p_tlas; sc.obj_lo = p_obj_lo; sc.obj_hi = p_obj_hi; sc.materials = p_materials;                     \
     sc.textures = p_textures; sc.texture_data = p_texdata; sc.n_objects = ss.n_objects;                                 \
     sc.n_texture_data = ss.n_texture_data; sc.tlas_root = ss.tlas_root; sc.cull_boxes = ss.cull_boxes;                  \
     sc._pad0 = 0; sc.tie_lowest = ss.tie_lowest; sc._pad1 = 0;                                                       \
-    sc.obj_slab = nullptr; sc.lb_nodes = nullptr; sc.lb_tris = nullptr; sc.lb_mesh = 0xFFFFFFFFu; sc.lb_node_base = 0;
+    sc.obj_slab = nullptr; sc.lb_nodes = nullptr; sc.lb_tris = nullptr; sc.lb_tri_ids = nullptr;                        \
+    sc.lb_mesh = 0xFFFFFFFFu; sc.lb_node_base = 0; sc.tlas_top = nullptr; sc.tlas_top_n = 0;
 
 // Per-frame constants.
 struct FrameParams {

@@ -172,44 +172,97 @@ PT_DEV bool slab_test_sel(const SlabRaySel& s, const float* box, float tmax, flo
     return tn <= tf;
 }
 
-// Per-lane stack walk of a binary BVH in "while-while" form: every lane first descends through internal nodes
-// until it holds a leaf (or runs out of work), then the lanes that hold a leaf process it together. This keeps the
-// expensive leaf code (object or triangle test) running with as many lanes as possible. The descent is cut after
-// BURST nodes: with incoherent rays a few lanes on long descents would otherwise hold back every lane that
-// already has its leaf. Measured best: 2 where a leaf is one triangle test, 16 where it is a whole object test.
+// ---- the 4-wide trees ---------------------------------------------------------------------------------------------
+// Ray constants for the child-box tests of a WNode: per axis the reciprocal direction, the constants of the near and of
+// the far plane (chosen by the sign of the direction, as in SlabRaySel) and that sign.
+struct WideRay {
+    v3 inv, kn, kf;
+    bool nx, ny, nz;
+};
+PT_DEV WideRay make_wide_ray(const SlabRay& s) {
+    WideRay r;
+    r.nx = (__float_as_uint(s.inv.x) >> 31) != 0u;
+    r.ny = (__float_as_uint(s.inv.y) >> 31) != 0u;
+    r.nz = (__float_as_uint(s.inv.z) >> 31) != 0u;
+    r.inv = s.inv;
+    r.kn = V3(r.nx ? s.kb.x : s.ka.x, r.ny ? s.kb.y : s.ka.y, r.nz ? s.kb.z : s.ka.z);
+    r.kf = V3(r.nx ? s.ka.x : s.kb.x, r.ny ? s.ka.y : s.kb.y, r.nz ? s.ka.z : s.kb.z);
+    return r;
+}
+
+#define PT_WALK_DONE 0x7FFFFFFFu
+// One visit of a wide node (its four 16-byte parts in q0..q3): tests the child boxes, continues with the child the ray
+// enters first and pushes the other children it hits so that the nearer one is popped first. Returns the next node
+// reference (a node, a leaf, or PT_WALK_DONE when nothing is hit and the stack is back at `sp0`).
+// A plane distance is  (origin + q * step - ray_origin -+ pad) * inv  =  fma(q, step * inv, fma(origin, inv, k)):
+// step is a power of two, so step * inv is exact, and the two fused operations stay well inside the pads (the ray's, in
+// k, and the 2^-20 of the node's size its boxes were grown by when they were put on the grid).
+// The three stack writes are unconditional: entries that are not pushed land just above the new top, so the stack has
+// three words of headroom (stack_depth_needed() on the host side).
+template <bool STATS>
+PT_DEV uint32_t wide_visit(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const WideRay& wr, float tmax,
+                           LdsStack stk, int& sp, int sp0, LaneCounters& cnt) {
+    const uint32_t exps = q0.w;
+    const float sx = __uint_as_float((exps << 23) & 0x7F800000u) * wr.inv.x;
+    const float sy = __uint_as_float((exps << 15) & 0x7F800000u) * wr.inv.y;
+    const float sz = __uint_as_float((exps << 7) & 0x7F800000u) * wr.inv.z;
+    const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
+    const float bnx = pt_fma(ox, wr.inv.x, wr.kn.x), bfx = pt_fma(ox, wr.inv.x, wr.kf.x);
+    const float bny = pt_fma(oy, wr.inv.y, wr.kn.y), bfy = pt_fma(oy, wr.inv.y, wr.kf.y);
+    const float bnz = pt_fma(oz, wr.inv.z, wr.kn.z), bfz = pt_fma(oz, wr.inv.z, wr.kf.z);
+    // q2 = (qlo.x, qlo.y, qlo.z, qhi.x), q3 = (qhi.y, qhi.z, -, -)
+    const uint32_t wnx = wr.nx ? q2.w : q2.x, wfx = wr.nx ? q2.x : q2.w;
+    const uint32_t wny = wr.ny ? q3.x : q2.y, wfy = wr.ny ? q2.y : q3.x;
+    const uint32_t wnz = wr.nz ? q3.y : q2.z, wfz = wr.nz ? q2.z : q3.y;
+    uint32_t key[4], ref[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float nx = pt_fma((float)((wnx >> (8 * k)) & 0xFFu), sx, bnx), fx = pt_fma((float)((wfx >> (8 * k)) & 0xFFu), sx, bfx);
+        const float ny = pt_fma((float)((wny >> (8 * k)) & 0xFFu), sy, bny), fy = pt_fma((float)((wfy >> (8 * k)) & 0xFFu), sy, bfy);
+        const float nz = pt_fma((float)((wnz >> (8 * k)) & 0xFFu), sz, bnz), fz = pt_fma((float)((wfz >> (8 * k)) & 0xFFu), sz, bfz);
+        const float tn = pt_max(pt_max(nx, ny), pt_max(nz, 0.0f));
+        const float tf = pt_min(pt_min(fx, fy), pt_min(fz, tmax));
+        const bool hit = (ref[k] != PT_NONE) && (tn <= tf);
+        key[k] = hit ? __float_as_uint(tn) : 0xFFFFFFFFu;   // tn >= 0: its bit pattern orders like its value
+        if (STATS && ref[k] != PT_NONE) cnt.box_tests++;
+    }
+    // sort the four (entry distance, child) pairs, nearest first
+#define PT_CE(a, b) { const bool sw_ = key[b] < key[a]; const uint32_t ka_ = sw_ ? key[b] : key[a], kb_ = sw_ ? key[a] : key[b]; \
+                      const uint32_t ra_ = sw_ ? ref[b] : ref[a], rb_ = sw_ ? ref[a] : ref[b]; key[a] = ka_; key[b] = kb_; ref[a] = ra_; ref[b] = rb_; }
+    PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+    const int n_hit = (key[0] != 0xFFFFFFFFu) + (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
+    const int n_push = n_hit > 1 ? n_hit - 1 : 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) stk.put(sp + ((key[j] != 0xFFFFFFFFu) ? n_push - j : n_push + j - 1), ref[j]);
+    sp += n_push;
+    if (n_hit) return ref[0];
+    return (sp > sp0) ? stk.get(--sp) : PT_WALK_DONE;
+}
+
+// Per-lane stack walk of a wide tree in "while-while" form: every lane first descends through nodes until it holds a
+// leaf (or runs out of work), then the lanes that hold a leaf process it together. This keeps the expensive leaf code
+// (object or triangle test) running with as many lanes as possible. The descent is cut after BURST nodes: with
+// incoherent rays a few lanes on long descents would otherwise hold back every lane that already has its leaf.
 #ifndef PT_BURST_BLAS
 #define PT_BURST_BLAS 2
 #endif
 #ifndef PT_BURST_TLAS
-#define PT_BURST_TLAS 16
+#define PT_BURST_TLAS 8
 #endif
-// `tmax` is read through the reference every time, so leaves that shorten the ray tighten the culling at once.
-#define PT_WALK_DONE 0x7FFFFFFFu
-template <bool STATS, int BURST, class LeafFn>
-PT_DEV void bvh_walk(const BvhNode* __restrict__ nodes, uint32_t bias, uint32_t root, const SlabRay& sr, const float& tmax, LdsStack stk,
-                     int sp0, bool active, LaneCounters& cnt, LeafFn leaf) {
+// `node_at(ref)` gives the address of a node as a pointer to its four 16-byte parts. `tmax` is read through the
+// reference every time, so leaves that shorten the ray tighten the culling at once. `leaf(ref, sp)` gets the child
+// reference without PT_LEAF_BIT.
+template <bool STATS, int BURST, class NodeFn, class LeafFn>
+PT_DEV void wide_walk(NodeFn node_at, uint32_t root, const WideRay& wr, const float& tmax, LdsStack stk, int sp0, bool active,
+                      LaneCounters& cnt, LeafFn leaf) {
     uint32_t node = active ? root : PT_WALK_DONE;
     int sp = sp0;
     while (__any(node != PT_WALK_DONE)) {
         for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
-            const BvhNode* N = &nodes[node - bias];   // bias: first node of a tree that was copied somewhere on its own
-            float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
-            if (STATS) cnt.box_tests += 2;
-            float tl, tr;
-            bool hit_l = slab_test(sr, ll, hl, tmax, tl);
-            bool hit_r = slab_test(sr, lr, hr, tmax, tr);
-            uint32_t cl = __float_as_uint(ll.w), cr = __float_as_uint(lr.w);
-            if (hit_l && hit_r) {
-                bool left_first = tl <= tr;
-                stk.put(sp++, left_first ? cr : cl);
-                node = left_first ? cl : cr;
-            } else if (hit_l) {
-                node = cl;
-            } else if (hit_r) {
-                node = cr;
-            } else {
-                node = (sp > sp0) ? stk.get(--sp) : PT_WALK_DONE;
-            }
+            const uint4* N = node_at(node);
+            const uint4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
+            node = wide_visit<STATS>(q0, q1, q2, q3, wr, tmax, stk, sp, sp0, cnt);
         }
         if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
             leaf(node & ~PT_LEAF_BIT, sp);
@@ -226,9 +279,9 @@ struct WalkState {
     uint32_t node;  // PT_WALK_DONE: no walk in progress
     int sp;
 };
-template <bool STATS, int BURST, class LeafFn>
-PT_DEV void bvh_walk_resume(const BvhNode* __restrict__ nodes, const SlabRay& sr, const float& tmax, LdsStack stk, WalkState& ws,
-                            uint32_t quota, LaneCounters& cnt, LeafFn leaf) {
+template <bool STATS, int BURST, class NodeFn, class LeafFn>
+PT_DEV void wide_walk_resume(NodeFn node_at, const WideRay& wr, const float& tmax, LdsStack stk, WalkState& ws, uint32_t quota,
+                             LaneCounters& cnt, LeafFn leaf) {
     uint32_t node = ws.node;
     int sp = ws.sp;
     const uint32_t walking = (uint32_t)__popcll(__ballot(node != PT_WALK_DONE));
@@ -238,24 +291,9 @@ PT_DEV void bvh_walk_resume(const BvhNode* __restrict__ nodes, const SlabRay& sr
         if (still <= stop_at) break;
         for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
             PT_COUNT(cnt, 8); PT_COUNT_LANES(cnt, 13, true);
-            const BvhNode* N = &nodes[node];
-            float4 ll = N->lo_l, hl = N->hi_l, lr = N->lo_r, hr = N->hi_r;
-            if (STATS) cnt.box_tests += 2;
-            float tl, tr;
-            bool hit_l = slab_test(sr, ll, hl, tmax, tl);
-            bool hit_r = slab_test(sr, lr, hr, tmax, tr);
-            uint32_t cl = __float_as_uint(ll.w), cr = __float_as_uint(lr.w);
-            if (hit_l && hit_r) {
-                bool left_first = tl <= tr;
-                stk.put(sp++, left_first ? cr : cl);
-                node = left_first ? cl : cr;
-            } else if (hit_l) {
-                node = cl;
-            } else if (hit_r) {
-                node = cr;
-            } else {
-                node = (sp > 0) ? stk.get(--sp) : PT_WALK_DONE;
-            }
+            const uint4* N = node_at(node);
+            const uint4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
+            node = wide_visit<STATS>(q0, q1, q2, q3, wr, tmax, stk, sp, 0, cnt);
         }
         if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
             PT_COUNT(cnt, 9); PT_COUNT_LANES(cnt, 14, true);
@@ -308,10 +346,17 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                 changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, best, cnt);
             }
         } else {
-            const SlabRay sr = make_slab_ray(lo, ld, pad);
-            bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, 0u, root, sr, best.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
-                const DTri* T = &sc.tris[tri_first + tri];
-                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, best, cnt);
+            const WideRay wr = make_wide_ray(make_slab_ray(lo, ld, pad));
+            const WNode* nodes = sc.blas_nodes;
+            const DTri* tris = sc.tris + tri_first;
+            const uint32_t* ids = sc.tri_ids + tri_first;
+            wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r) { return reinterpret_cast<const uint4*>(nodes + r); }, root, wr, best.t, stk, sp0, true, cnt,
+                                            [&](uint32_t leaf, int) {
+                const uint32_t pos = leaf & PT_WLEAF_POS_MASK, n = (leaf >> PT_WLEAF_COUNT_SHIFT) + 1u;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const DTri* T = &tris[pos + j];
+                    changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, ids[pos + j], sc.tie_lowest, best, cnt);
+                }
             });
         }
         if (changed) {
@@ -348,24 +393,26 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                             if (inside) changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
                         }
                     }
-                } else if (LB && m == sc.lb_mesh) {
-                    // this mesh's BLAS sits in LDS: a node visit costs an LDS read instead of a trip to the L2
-                    if (sc.lb_tris) {
-                        bvh_walk<STATS, PT_BURST_BLAS>(sc.lb_nodes, sc.lb_node_base, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
-                            const DTri* T = &sc.lb_tris[tri];
-                            changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
-                        });
-                    } else {
-                        bvh_walk<STATS, PT_BURST_BLAS>(sc.lb_nodes, sc.lb_node_base, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
-                            const DTri* T = &sc.tris[tri_first + tri];
-                            changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
-                        });
-                    }
                 } else {
-                    bvh_walk<STATS, PT_BURST_BLAS>(sc.blas_nodes, 0u, root, sr, cand.t, stk, sp0, true, cnt, [&](uint32_t tri, int) {
-                        const DTri* T = &sc.tris[tri_first + tri];
-                        changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri, sc.tie_lowest, cand, cnt);
-                    });
+                    const WideRay wr = make_wide_ray(sr);
+                    auto walk = [&](const WNode* nodes, const DTri* tris, const uint32_t* ids) {
+                        wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r) { return reinterpret_cast<const uint4*>(nodes + r); }, root, wr, cand.t, stk, sp0, true, cnt,
+                                                        [&](uint32_t leaf, int) {
+                            const uint32_t pos = leaf & PT_WLEAF_POS_MASK, n = (leaf >> PT_WLEAF_COUNT_SHIFT) + 1u;
+                            for (uint32_t j = 0; j < n; ++j) {
+                                const DTri* T = &tris[pos + j];
+                                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, ids[pos + j], sc.tie_lowest, cand, cnt);
+                            }
+                        });
+                    };
+                    // (separate calls, so that each one's loads are plain LDS or plain global-memory loads)
+                    if (LB && m == sc.lb_mesh) {
+                        // this mesh's BLAS sits in LDS: a node visit costs an LDS read instead of a trip to the L2
+                        if (sc.lb_tris) walk(sc.lb_nodes - sc.lb_node_base, sc.lb_tris, sc.lb_tri_ids);
+                        else walk(sc.lb_nodes - sc.lb_node_base, sc.tris + tri_first, sc.tri_ids + tri_first);
+                    } else {
+                        walk(sc.blas_nodes, sc.tris + tri_first, sc.tri_ids + tri_first);
+                    }
                 }
                 if (changed) {
                     const float t_aabb = hit_box_exact(me->bmin, me->bmax, lo, ld);   // reference :77-80
@@ -438,12 +485,18 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
     }
 }
 
+// A TLAS node: from the copy of the tree's top levels in LDS when the kernel made one, else from global memory.
+PT_DEV const uint4* tlas_node_at(const SceneView& sc, uint32_t r) {
+    const WNode* n = (r < sc.tlas_top_n) ? sc.tlas_top + r : sc.tlas_nodes + r;
+    return reinterpret_cast<const uint4*>(n);
+}
+
 // hit_all through the TLAS: each lane walks the object tree on its own.
 template <bool STATS>
 PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
     if (sc.tlas_root == PT_NONE) return;
-    const SlabRay sr = world_slab_ray(ro, rd);
-    bvh_walk<STATS, PT_BURST_TLAS>(sc.tlas_nodes, 0u, sc.tlas_root, sr, best.t, stk, 0, active, cnt,
+    const WideRay wr = make_wide_ray(world_slab_ray(ro, rd));
+    wide_walk<STATS, PT_BURST_TLAS>([&](uint32_t r) { return tlas_node_at(sc, r); }, sc.tlas_root, wr, best.t, stk, 0, active, cnt,
                     [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, ro, rd, best, stk, sp, cnt); });
 }
 
@@ -473,7 +526,7 @@ PT_DEV HitInfo finalize_hit(const SceneView& sc, v3 ro, v3 rd, const Best& b) {
     h.v = 0.0f;
     if (b.obj == PT_NONE) return h;
     const DObject* ob = &sc.objects[b.obj];
-    Affine w2l = ob->w2l, l2w = ob->l2w;
+    const Affine w2l = ob->w2l, l2w = sc.obj_l2w[b.obj];
     v3 lo = xform_point(w2l, ro);
     v3 ld = xform_dir(w2l, rd);
     const DTriAttr* A = &sc.tri_attrs[ob->tri_first + b.tri];
