@@ -106,7 +106,7 @@ struct pt_ctx {
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors, t_ranges, t_work, t_tris_tmp;
     // frame outputs
-    DevBuf d_out, d_out16, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_rays, d_hits, d_paths, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
+    DevBuf d_stack_overflow, d_out, d_out16, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_rays, d_hits, d_paths, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
@@ -118,6 +118,7 @@ struct pt_ctx {
     uint32_t max_blas_need = 0, tlas_need = 0;   // traversal stack entries a BLAS / the TLAS walk can need
     uint32_t tlas_n_wide = 0;                    // nodes of the TLAS
     uint32_t tlas_top_max = 128;                 // nodes of its top levels k_paths stages in LDS at most
+    uint32_t lds_stack_max = 16;                 // PT_MODE_TLAS, k_paths: traversal stack entries per lane kept in LDS
     bool have_meshes = false, have_materials = false, have_objects = false;
     bool objects_built = false;   // the instance data on the device was derived from h_objects and the current meshes
     bool use_tlas = false;
@@ -259,6 +260,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = true;
         if (const char* e = std::getenv("PT_AMD_WALK_QUOTA")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->walk_quota = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_BLAS_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= (int)PT_WIDE_MAX_LEAF) ctx->blas_max_leaf = (uint32_t)v; }
+        if (const char* e = std::getenv("PT_AMD_LDS_STACK")) { int v = std::atoi(e); if (v >= 4 && v <= (int)kMaxStackDepth) ctx->lds_stack_max = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_TLAS_TOP")) { int v = std::atoi(e); if (v >= 0 && v <= 2048) ctx->tlas_top_max = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_LDS_BLAS")) ctx->lds_blas = false;
         if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
@@ -316,7 +318,7 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_out16, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
                       &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log,
-                      &ctx->d_tri_ids, &ctx->d_blas_bnodes, &ctx->d_blas_order, &ctx->d_obj_l2w, &ctx->d_tlas_bnodes, &ctx->t_ranges, &ctx->t_work, &ctx->t_tris_tmp};
+                      &ctx->d_stack_overflow, &ctx->d_tri_ids, &ctx->d_blas_bnodes, &ctx->d_blas_order, &ctx->d_obj_l2w, &ctx->d_tlas_bnodes, &ctx->t_ranges, &ctx->t_work, &ctx->t_tris_tmp};
     for (DevBuf* b : bufs) b->release();
     for (void* p : ctx->host_allocs) (void)hipHostFree(p);
     for (FrameSlot& sl : ctx->slot) {
@@ -975,7 +977,10 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         pp.chunk = ctx->chunk_pixels;
         // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
         pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
-        const size_t lds = ((size_t)4 * (depth + lane_slots(mode)) * 64 + 4 * PT_SCHED_WORDS) * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
+        // PT_MODE_TLAS: the first lds_stack_max entries of a lane's traversal stack live in LDS, the rest (seldom reached)
+        // in global memory, so that the stack does not decide how many workgroups a compute unit holds
+        const uint32_t depth_paths = (mode == PT_MODE_TLAS && !noalloc) ? std::min(depth, ctx->lds_stack_max) : depth;
+        const size_t lds = ((size_t)4 * (depth_paths + lane_slots(mode)) * 64 + 4 * PT_SCHED_WORDS) * sizeof(uint32_t) + (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
         using PathsFn = void (*)(PT_SCENE_PARAMS, LdsScene, LdsBlas, PathParams, uint32_t, const PathRec*, PathCarry*, uint32_t*, const uint32_t*, const ChunkOrderInfo*, float4*,
                                  uint32_t*, DCounters*, uint4*);
         static const PathsFn ptable[4][2] = {{k_paths<PT_MODE_LIST, false>, k_paths<PT_MODE_LIST, true>},
@@ -1002,7 +1007,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
                 lb.node_base = ctx->h_blas_nodes_base[best];
                 lb.n_nodes = ctx->h_blas_n_wide[best];
                 lb.tri_first = ctx->h_meshes[best].tri_first;
-                lb.n_tris = (lds_blas_bytes(lb.n_nodes, ctx->h_meshes[best].tri_count) <= budget) ? ctx->h_meshes[best].tri_count : 0u;
+                lb.n_tris = (lds_blas_bytes(lb.n_nodes, ctx->h_meshes[best].tri_count) <= budget && !std::getenv("PT_AMD_LDS_BLAS_NODES_ONLY")) ? ctx->h_meshes[best].tri_count : 0u;
                 paths_mode = PT_MODE_LIST_LB;
             }
         }
@@ -1051,7 +1056,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             wlog = ctx->d_wave_log.as<uint4>();
             ctx->wave_log_records = grid * 4u;
         }
-        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u chunk=%u refill_min=%u sweeps=%u last_n_paths=%llu\n", paths_mode, per_cu, grid, lds_paths, depth, pp.chunk, pp.refill_min, pp.n_sweeps, (unsigned long long)ctx->last_n_paths);
+        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u/%u tlas: nodes=%u levels=%u need=%u top=%u chunk=%u refill_min=%u sweeps=%u last_n_paths=%llu\n", paths_mode, per_cu, grid, lds_paths, depth_paths, depth, ctx->tlas_n_wide, ctx->tlas_depth, ctx->tlas_need, pp.tlas_top_n, pp.chunk, pp.refill_min, pp.n_sweeps, (unsigned long long)ctx->last_n_paths);
         const uint32_t* chunk_order = nullptr;
         const ChunkOrderInfo* order_info = nullptr;
         if (use_hint && pp.chunk == PT_CHUNK) {
@@ -1065,7 +1070,12 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             chunk_order = order;
             order_info = info;
         }
-        fn<<<grid, 256, lds_paths, s>>>(PT_SCENE_ARGS(sv), ls, lb, pp, depth, recs, w.carry, w.sweeps_done, chunk_order,
+        pp.stack_overflow = nullptr;
+        if (depth_paths < depth) {
+            PT_HIP(ctx, ctx->d_stack_overflow.ensure(sizeof(uint32_t) * (size_t)(depth - depth_paths) * grid * 256));
+            pp.stack_overflow = ctx->d_stack_overflow.as<uint32_t>();
+        }
+        fn<<<grid, 256, lds_paths, s>>>(PT_SCENE_ARGS(sv), ls, lb, pp, depth_paths, recs, w.carry, w.sweeps_done, chunk_order,
                                   order_info, o4, ar, dc, wlog);
         PT_HIP(ctx, hipGetLastError());
     }

@@ -18,10 +18,15 @@
 
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "pt_trace.h"
 
 #ifndef PT_PATHS_MIN_WAVES
 #define PT_PATHS_MIN_WAVES 4   // waves per SIMD k_paths is compiled for (caps its VGPR allocation)
+#endif
+#ifndef PT_PATHS_MIN_WAVES_TLAS
+#define PT_PATHS_MIN_WAVES_TLAS 4   // ... its PT_MODE_TLAS variant
 #endif
 
 // One entry of the path list: what k_primary found for a pixel that needs paths. 64 B, constant during k_paths.
@@ -64,6 +69,7 @@ struct PathParams {
     uint32_t sweep_end[8];  // slice j runs samples [sweep_end[j-1], sweep_end[j]); sweep_end[n_sweeps-1] == samples
     uint32_t split_chunks;  // 1: the most expensive chunks are handed out in parts (ChunkOrderInfo::n_split)
     uint32_t tlas_top_n;    // PT_MODE_TLAS: nodes of the TLAS (its top levels) every workgroup copies into LDS
+    uint32_t* stack_overflow;  // PT_MODE_TLAS: traversal stack entries beyond the `stack_depth` kept in LDS, [entry][lane of the grid]
 };
 #define PT_MAX_SWEEPS 8
 
@@ -414,7 +420,7 @@ __host__ __device__ constexpr uint32_t lane_slots(int mode) { return mode == PT_
 #define PT_SCHED_WORDS 8
 
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, LdsBlas lb, PathParams pp, uint32_t stack_depth,
+__global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS : PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, LdsBlas lb, PathParams pp, uint32_t stack_depth,
                                                                     const PathRec* __restrict__ recs, PathCarry* __restrict__ carry,
                                                                     uint32_t* __restrict__ sweeps_done, const uint32_t* __restrict__ chunk_order,
                                                                     const ChunkOrderInfo* __restrict__ order_info,
@@ -429,8 +435,14 @@ __global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARA
     if (MODE == PT_MODE_LIST_LB) stage_blas_in_lds(sc, lb, s_mem + lds_fixed);
     if (MODE == PT_MODE_TLAS) stage_tlas_top_in_lds(sc, pp.tlas_top_n, s_mem + lds_fixed);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    LdsStack stk;
+    // (the TLAS walk keeps only the first stack_depth entries of its stack in LDS)
+    typename std::conditional<MODE == PT_MODE_TLAS, SpillStack, LdsStack>::type stk;
     stk.base = &s_mem[wave * stack_depth * 64 + lane];
+    if constexpr (MODE == PT_MODE_TLAS) {
+        stk.overflow = pp.stack_overflow + (blockIdx.x * 256u + threadIdx.x);
+        stk.lds_levels = (int)stack_depth;
+        stk.stride = gridDim.x * 256u;
+    }
     uint32_t* slot_u = &s_mem[4 * stack_depth * 64 + wave * SLOTS * 64 + lane];  // slot[k * 64]
     float* slot = reinterpret_cast<float*>(slot_u);
     uint32_t* sched = &s_mem[4 * (stack_depth + SLOTS) * 64 + wave * PT_SCHED_WORDS];

@@ -53,6 +53,23 @@ struct LdsStack {
     PT_DEV void put(int level, uint32_t v) { base[level * 64] = v; }
     PT_DEV uint32_t get(int level) const { return base[level * 64]; }
 };
+// The same with only the first `lds_levels` entries in LDS and the rest in a column of global memory per lane: a walk
+// rarely holds more than a dozen entries, but the trees allow several times that, and LDS per workgroup decides how many
+// waves a compute unit holds. A lane reads back only what it wrote itself, so no ordering beyond program order is needed.
+struct SpillStack {
+    uint32_t* base;      // &s_stack[wave][0][lane]
+    uint32_t* overflow;  // this lane's column: entry k at overflow[k * stride]
+    int lds_levels;
+    uint32_t stride;
+    PT_DEV void put(int level, uint32_t v) {
+        if (level < lds_levels) base[level * 64] = v;
+        else overflow[(size_t)(level - lds_levels) * stride] = v;
+    }
+    PT_DEV uint32_t get(int level) const {
+        if (level < lds_levels) return base[level * 64];
+        return overflow[(size_t)(level - lds_levels) * stride];
+    }
+};
 
 PT_DEV bool candidate_wins(float t, uint32_t obj, uint32_t tri, const Best& b, uint32_t tie_lowest) {
     if (t < b.t) return true;
@@ -199,9 +216,9 @@ PT_DEV WideRay make_wide_ray(const SlabRay& s) {
 // k, and the 2^-20 of the node's size its boxes were grown by when they were put on the grid).
 // The three stack writes are unconditional: entries that are not pushed land just above the new top, so the stack has
 // three words of headroom (stack_depth_needed() on the host side).
-template <bool STATS>
+template <bool STATS, class Stk>
 PT_DEV uint32_t wide_visit(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const WideRay& wr, float tmax,
-                           LdsStack stk, int& sp, int sp0, LaneCounters& cnt) {
+                           Stk stk, int& sp, int sp0, LaneCounters& cnt) {
     const uint32_t exps = q0.w;
     const float sx = __uint_as_float((exps << 23) & 0x7F800000u) * wr.inv.x;
     const float sy = __uint_as_float((exps << 15) & 0x7F800000u) * wr.inv.y;
@@ -253,8 +270,8 @@ PT_DEV uint32_t wide_visit(const uint4 q0, const uint4 q1, const uint4 q2, const
 // `node_at(ref)` gives the address of a node as a pointer to its four 16-byte parts. `tmax` is read through the
 // reference every time, so leaves that shorten the ray tighten the culling at once. `leaf(ref, sp)` gets the child
 // reference without PT_LEAF_BIT.
-template <bool STATS, int BURST, class NodeFn, class LeafFn>
-PT_DEV void wide_walk(NodeFn node_at, uint32_t root, const WideRay& wr, const float& tmax, LdsStack stk, int sp0, bool active,
+template <bool STATS, int BURST, class NodeFn, class LeafFn, class Stk>
+PT_DEV void wide_walk(NodeFn node_at, uint32_t root, const WideRay& wr, const float& tmax, Stk stk, int sp0, bool active,
                       LaneCounters& cnt, LeafFn leaf) {
     uint32_t node = active ? root : PT_WALK_DONE;
     int sp = sp0;
@@ -262,7 +279,7 @@ PT_DEV void wide_walk(NodeFn node_at, uint32_t root, const WideRay& wr, const fl
         for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
             const uint4* N = node_at(node);
             const uint4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
-            node = wide_visit<STATS>(q0, q1, q2, q3, wr, tmax, stk, sp, sp0, cnt);
+            node = wide_visit<STATS, Stk>(q0, q1, q2, q3, wr, tmax, stk, sp, sp0, cnt);
         }
         if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
             leaf(node & ~PT_LEAF_BIT, sp);
@@ -279,8 +296,8 @@ struct WalkState {
     uint32_t node;  // PT_WALK_DONE: no walk in progress
     int sp;
 };
-template <bool STATS, int BURST, class NodeFn, class LeafFn>
-PT_DEV void wide_walk_resume(NodeFn node_at, const WideRay& wr, const float& tmax, LdsStack stk, WalkState& ws, uint32_t quota,
+template <bool STATS, int BURST, class NodeFn, class LeafFn, class Stk>
+PT_DEV void wide_walk_resume(NodeFn node_at, const WideRay& wr, const float& tmax, Stk stk, WalkState& ws, uint32_t quota,
                              LaneCounters& cnt, LeafFn leaf) {
     uint32_t node = ws.node;
     int sp = ws.sp;
@@ -293,7 +310,7 @@ PT_DEV void wide_walk_resume(NodeFn node_at, const WideRay& wr, const float& tma
             PT_COUNT(cnt, 8); PT_COUNT_LANES(cnt, 13, true);
             const uint4* N = node_at(node);
             const uint4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
-            node = wide_visit<STATS>(q0, q1, q2, q3, wr, tmax, stk, sp, 0, cnt);
+            node = wide_visit<STATS, Stk>(q0, q1, q2, q3, wr, tmax, stk, sp, 0, cnt);
         }
         if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
             PT_COUNT(cnt, 9); PT_COUNT_LANES(cnt, 14, true);
@@ -312,8 +329,8 @@ PT_DEV void wide_walk_resume(NodeFn node_at, const WideRay& wr, const float& tma
 // three divisions is then needed once per accepted object instead of once per visited object).
 // Meshes without a BLAS and more than this many triangles are first tested against their padded local box.
 #define PT_LOCAL_BOX_MIN_TRIS 4u
-template <bool STATS, bool PERLANE, bool LB = false>
-PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& best, LdsStack stk, int sp0,
+template <bool STATS, bool PERLANE, bool LB = false, class Stk>
+PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& best, Stk stk, int sp0,
                         LaneCounters& cnt) {
     const DObject* ob = &sc.objects[obj];
     const Affine w2l = ob->w2l;
@@ -432,8 +449,8 @@ PT_DEV SlabRay world_slab_ray(v3 ro, v3 rd) {
 // each lane collects its own candidates in a bit mask and then works through them.
 // An object whose world box the ray misses cannot contain an accepted triangle, so skipping it changes nothing.
 // With sc.cull_boxes == 0 (PT_ACCEL_BRUTE) every object is a candidate: the reference's exhaustive loop.
-template <bool STATS, bool PERLANE, bool LB = false>
-PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
+template <bool STATS, bool PERLANE, bool LB = false, class Stk>
+PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, Stk stk, LaneCounters& cnt) {
 #ifdef PT_EXEC_COUNTS
     unsigned long long tc = __builtin_amdgcn_s_memtime();
 #endif
@@ -492,8 +509,8 @@ PT_DEV const uint4* tlas_node_at(const SceneView& sc, uint32_t r) {
 }
 
 // hit_all through the TLAS: each lane walks the object tree on its own.
-template <bool STATS>
-PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
+template <bool STATS, class Stk>
+PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, Stk stk, LaneCounters& cnt) {
     if (sc.tlas_root == PT_NONE) return;
     const WideRay wr = make_wide_ray(world_slab_ray(ro, rd));
     wide_walk<STATS, PT_BURST_TLAS>([&](uint32_t r) { return tlas_node_at(sc, r); }, sc.tlas_root, wr, best.t, stk, 0, active, cnt,
@@ -505,8 +522,8 @@ PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
 #define PT_MODE_TLAS 1  // TLAS walk
 #define PT_MODE_LDS 2   // object list, every scene record staged in LDS (small scenes)
 #define PT_MODE_LIST_LB 3  // object list, the BLAS of one mesh staged in LDS (k_paths only)
-template <int MODE, bool STATS>
-PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, LdsStack stk, LaneCounters& cnt) {
+template <int MODE, bool STATS, class Stk>
+PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, Stk stk, LaneCounters& cnt) {
     best.t = PT_T_MAX;
     best.obj = PT_NONE;
     best.tri = PT_NONE;

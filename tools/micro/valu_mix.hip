@@ -1,8 +1,10 @@
 // Microbenchmark: issue cost per wave64 instruction of the VALU instructions the path kernels are made of, with 4 waves
-// per SIMD (the occupancy k_paths runs at), eight independent chains per wave. Also reports the shader clock from the
+// per SIMD (the occupancy k_paths runs at; `valu_mix N` runs a short list with N = 1..8 waves per SIMD instead), eight
+// independent chains per wave. Also reports the shader clock from the
 // ratio of s_memtime to the constant 100 MHz s_memrealtime.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 template <int OP>
 __global__ __launch_bounds__(64) void k(float* out, int iters, unsigned long long* cyc) {
@@ -55,8 +57,9 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, unsigned long lon
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = r1 - r0; }
 }
+static int g_wps = 4;
 template <int OP> void run(const char* name, float* out, unsigned long long* cyc) {
-    const int iters = 2000, wps = 4, blocks = 256 * 4 * wps;
+    const int iters = 2000, wps = g_wps, blocks = 256 * 4 * wps;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
@@ -67,12 +70,21 @@ template <int OP> void run(const char* name, float* out, unsigned long long* cyc
     }
     unsigned long long c[2]; hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost);
     const double inst = (double)iters * 64, ghz = (double)c[0] / ((double)c[1] * 10.0);
-    printf("%-28s %.3f ms  clock %.2f GHz  SIMD cycles per instruction %.2f\n", name, ms, ghz, ms * 1e-3 * ghz * 1e9 / (inst * wps));
+    printf("%-28s waves/SIMD %d  %.3f ms  clock %.2f GHz  SIMD cycles per instruction %.2f  (one wave's own cycles per instruction %.2f)\n", name, wps, ms, ghz,
+           ms * 1e-3 * ghz * 1e9 / (inst * wps), (double)c[0] / inst);
 }
-int main() {
+int main(int argc, char** argv) {
     setvbuf(stdout, NULL, _IONBF, 0);
     float* out; unsigned long long* cyc;
     hipMalloc(&out, 64 * 1024 * 64 * 4); hipMalloc(&cyc, 16);
+    if (argc > 1) {   // short list at another occupancy
+        g_wps = atoi(argv[1]);
+        if (g_wps < 1 || g_wps > 8) return 1;
+        run<0>("v_fma_f32", out, cyc); run<1>("v_pk_fma_f32", out, cyc); run<27>("v_mul_f32", out, cyc); run<3>("v_min_f32", out, cyc);
+        run<4>("v_max3_f32", out, cyc); run<15>("v_cndmask_e64 sgpr (indep)", out, cyc); run<18>("v_cvt_f32_u32", out, cyc);
+        run<13>("v_mov_b32", out, cyc); run<7>("v_rcp_f32", out, cyc); run<30>("s_add + s_and (2 salu)", out, cyc);
+        return 0;
+    }
     run<0>("v_fma_f32", out, cyc); run<1>("v_pk_fma_f32", out, cyc); run<2>("v_pk_mul_f32", out, cyc); run<12>("v_pk_add_f32", out, cyc);
     run<3>("v_min_f32", out, cyc); run<4>("v_max3_f32", out, cyc); run<5>("v_mul_lo_u32", out, cyc); run<11>("v_mul_u32_u24", out, cyc);
     run<9>("v_mad_u64_u32", out, cyc); run<6>("v_sqrt_f32", out, cyc); run<7>("v_rcp_f32", out, cyc); run<8>("v_cndmask_b32", out, cyc);
