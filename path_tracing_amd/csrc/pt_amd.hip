@@ -117,7 +117,7 @@ struct pt_ctx {
     uint32_t max_blas_depth = 0, tlas_depth = 0, tlas_root = PT_NONE;   // depths: levels of the 4-wide trees
     uint32_t max_blas_need = 0, tlas_need = 0;   // traversal stack entries a BLAS / the TLAS walk can need
     uint32_t tlas_n_wide = 0;                    // nodes of the TLAS
-    uint32_t tlas_top_max = 128;                 // nodes of its top levels k_paths stages in LDS at most
+    uint32_t tlas_top_max = PT_NONE;             // nodes of its top levels k_paths stages in LDS at most (PT_NONE: what fits beside four workgroups per compute unit)
     uint32_t lds_stack_max = 16;                 // PT_MODE_TLAS, k_paths: traversal stack entries per lane kept in LDS
     bool have_meshes = false, have_materials = false, have_objects = false;
     bool objects_built = false;   // the instance data on the device was derived from h_objects and the current meshes
@@ -134,7 +134,7 @@ struct pt_ctx {
     bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
     uint64_t last_n_paths = ~0ull; // entries of the path list of the last frame read back
     uint32_t walk_quota = 16;     // see PathParams::walk_quota
-    uint32_t blas_max_leaf = PT_WIDE_MAX_LEAF;   // triangles a BLAS leaf holds at most (1..4)
+    uint32_t blas_max_leaf = 2;   // triangles a BLAS leaf holds at most (1..PT_WIDE_MAX_LEAF); 2 measured best on the 968-triangle mesh of scene.glb
     bool split_chunks = false;    // see PathParams::split_chunks: shorter single frames on scenes of long BVH walks, fewer frames per second when several are in flight
     bool lds_blas = true;         // object-list scenes: stage the biggest BLAS that fits in LDS (k_paths)
     uint32_t lds_per_cu = 160 * 1024;
@@ -1012,7 +1012,13 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             }
         }
         // PT_MODE_TLAS: the top levels of the object tree, the nodes every ray passes, are copied into LDS
-        pp.tlas_top_n = (mode == PT_MODE_TLAS) ? std::min(ctx->tlas_n_wide, ctx->tlas_top_max) : 0u;
+        pp.tlas_top_n = 0;
+        if (mode == PT_MODE_TLAS) {
+            // as many as fit without costing a workgroup per compute unit (registers allow four)
+            const size_t share = ctx->lds_per_cu / 4 - 512;
+            const uint32_t fit = share > lds ? (uint32_t)((share - lds) / sizeof(WNode)) : 0u;
+            pp.tlas_top_n = std::min(ctx->tlas_n_wide, ctx->tlas_top_max == PT_NONE ? fit : ctx->tlas_top_max);
+        }
         const size_t lds_paths = lds + (paths_mode == PT_MODE_LIST_LB ? lds_blas_bytes(lb.n_nodes, lb.n_tris) : 0u) + (size_t)pp.tlas_top_n * sizeof(WNode);
         PathsFn fn = ptable[paths_mode][st ? 1 : 0];
         if (lds_paths > 64 * 1024) PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_paths));

@@ -262,7 +262,7 @@ PT_DEV uint32_t wide_visit(const uint4 q0, const uint4 q1, const uint4 q2, const
 // (object or triangle test) running with as many lanes as possible. The descent is cut after BURST nodes: with
 // incoherent rays a few lanes on long descents would otherwise hold back every lane that already has its leaf.
 #ifndef PT_BURST_BLAS
-#define PT_BURST_BLAS 2
+#define PT_BURST_BLAS 1
 #endif
 #ifndef PT_BURST_TLAS
 #define PT_BURST_TLAS 8
