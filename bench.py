@@ -14,6 +14,13 @@ bit-identical to the one-GPU image, strong scaling).
 Frames are kept in flight (--frames-in-flight, default 3): that many contexts take the frames in turn on their own
 streams, so the start of a frame overlaps the tail of the previous one; results are those of one context.
 
+Every step is a new frame the way the reference makes one (src/raytrace.wgsl:210, src/extract.rs:297-346): `time`
+advances, so every pixel draws new random numbers, and the object array is handed over again (unchanged, as the example
+scenes are static). The timed region of K steps is repeated (--repeats, fewer for workloads of seconds per repeat);
+`value` and `ms_per_step` are the median repeat, the fastest one is reported beside it. Two more timings of the same K
+steps are reported: one frame at a time on one context (what a caller of the synchronous pt_render sees, without the
+copy to the host), and with the schedule hints from the previous frame switched off (what a moving camera gets).
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -101,6 +108,9 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="contexts that take the frames in turn (1: strictly one frame at a time)")
+    ap.add_argument("--repeats", type=int, default=10, help="times the K-step timed region is run (median and minimum are reported); "
+                    "cut down so that the repeats of one timing take about 8 s at most")
+    ap.add_argument("--fixed-time", action="store_true", help="render the identical frame every step (time = this rank's constant) instead of advancing time")
     ap.add_argument("--multi-gpu", default="virtual_frames", choices=["virtual_frames", "tiles"],
                     help="N > 1: every GPU renders its own virtual frame (N x spp, weak scaling) or a share of the tiles of one frame (strong scaling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path with every rank on GPU 0")
@@ -158,15 +168,32 @@ def main():
     reduced = [torch.cuda.Event() for _ in bufs]
     step_no = [0]
 
-    def step():
-        k = step_no[0] % F
+    frames = [scene.frame(time=virtual_frame_time(rank), part_index=rank, part_count=world) if tiles else scene.frame(time=virtual_frame_time(rank))
+              for _ in range(F)]
+
+    def frame_time(i):
+        """`time` of this rank's i-th step: every rank and step its own virtual frame (tile split: all ranks render the same one)."""
+        if args.fixed_time:
+            return 0.0 if tiles else virtual_frame_time(rank)
+        return virtual_frame_time(i if tiles else i * world + rank)
+
+    def step(cs=None, one_at_a_time=False):
+        cs = cs or ctxs
+        n = len(cs)
+        i = step_no[0]
+        k = i % n
         step_no[0] += 1
         buf = bufs[k]
+        fr = frames[k]
+        fr.time = frame_time(i)
+        cs[k].upload_objects(scene.objects)      # extract_visible hands the objects over every frame; unchanged here
         if world == 1:
-            ctxs[k].render_device(frame, buf.data_ptr(), streams[k].cuda_stream)
+            cs[k].render_device(fr, buf.data_ptr(), streams[k].cuda_stream)
+            if one_at_a_time:
+                streams[k].synchronize()
             return
         streams[k].wait_event(reduced[k])        # this buffer's previous reduction (F steps ago) has finished
-        ctxs[k].render_device(frame, buf.data_ptr(), streams[k].cuda_stream)
+        cs[k].render_device(fr, buf.data_ptr(), streams[k].cuda_stream)
         rendered[k].record(streams[k])
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(rendered[k])
@@ -179,6 +206,8 @@ def main():
             if not tiles:
                 buf.mul_(1.0 / world)
             reduced[k].record(comm_stream)
+        if one_at_a_time:
+            comm_stream.synchronize()
 
     # one untimed frame per context: allocations, and the ray counts the next frame's schedule is derived from
     for k in range(F):
@@ -192,21 +221,54 @@ def main():
     detail = ctx.stats()
     ctx.set_stats_detail(False)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
+    def timed(cs=None, one_at_a_time=False, repeats=None):
+        """K steps between barrier + synchronize on both sides, `repeats` times; seconds per repeat (max over ranks)."""
+        for _ in range(args.warmup):
+            step(cs, one_at_a_time)
+        out_s = []
+        reps = repeats or args.repeats
+        r = 0
+        while r < reps:
+            torch.cuda.synchronize(device)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(cs, one_at_a_time)
+            torch.cuda.synchronize(device)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(device)
+            dt_r = time.perf_counter() - t0
+            if world > 1:
+                tm = torch.tensor([dt_r], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dt_r = float(tm[0].item())
+            out_s.append(dt_r)
+            r += 1
+            if r == 1 and not repeats:   # repeats of seconds each: fewer of them (every rank sees the same max-reduced time)
+                reps = max(1, min(reps, int(8.0 / max(dt_r, 1e-9))))
+        return out_s
+
+    times = timed()
+    dt = float(np.median(times))
+    dt_min = float(np.min(times))
     mean_img = float(bufs[(step_no[0] - 1) % F][..., :3].mean().item())   # the last (reduced) image
+    # rays of a step: the mean over the last frame of every context (the count moves by a fraction of a percent with `time`)
+    last = [c.stats() for c in ctxs]
+    n_rep_other = max(1, min(len(times), 5))
+    # the same K steps, one frame at a time on one context: each frame complete before the next is enqueued
+    times_one = timed([ctxs[0]], one_at_a_time=True, repeats=n_rep_other)
+    # ... and with the schedule hints off (the view changes every frame: the previous frame's ray counts say nothing)
+    os.environ["PT_AMD_NO_COST_HINTS"] = "1"
+    ctxs_nh = [abi.Context(device=local_rank) for _ in range(F)]
+    del os.environ["PT_AMD_NO_COST_HINTS"]
+    for c in ctxs_nh:
+        c.upload_scene(scene)
+    times_nh = timed(ctxs_nh, repeats=n_rep_other)
+    for c in ctxs_nh:
+        c.close()
 
     # kernel durations (HIP events recorded by the library on the launch stream), one step at a time
     kernel_ms, paths_ms, primary_ms = [], [], []
@@ -217,9 +279,8 @@ def main():
         kernel_ms.append(st["trace_ms"])
         paths_ms.append(st["paths_ms"])
         primary_ms.append(st["primary_ms"])
-    st = ctx.stats()
-
-    rays_local = int(st["rays"])
+    rays_local = int(round(float(np.mean([x["rays"] for x in last]))))
+    st = {"rays_reference": int(round(float(np.mean([x["rays_reference"] for x in last])))), "paths": last[0]["paths"]}
     t_max = dt
     rays_total = rays_local
     if world > 1:
@@ -277,6 +338,13 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "repeats": len(times),
+            "ms_per_step_min": round(dt_min / args.steps * 1e3, 4),
+            "ms_per_step_all_repeats": [round(t / args.steps * 1e3, 4) for t in times],
+            "ms_per_step_one_in_flight": round(float(np.median(times_one)) / args.steps * 1e3, 4),
+            "ms_per_step_no_hints": round(float(np.median(times_nh)) / args.steps * 1e3, 4),
+            "step_definition": "a new frame per step: time advances (new seeds for every pixel, src/raytrace.wgsl:210) and the unchanged object array is "
+                               "handed over again (src/extract.rs:297-346)" if not args.fixed_time else "the identical frame every step",
             "higher_is_better": True,
             "scaling": "strong" if tiles else "weak",
             "vs_baseline": None,
