@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=3, help="contexts that take the frames in turn (1: strictly one frame at a time)")
     ap.add_argument("--repeats", type=int, default=10, help="times the K-step timed region is run (median and minimum are reported); "
                     "cut down so that the repeats of one timing take about 8 s at most")
+    ap.add_argument("--only-timed", action="store_true", help="stop after the timed region and print a short line (for profiler passes: "
+                    "the last steps x repeats frames of the trace are then the timed region)")
     ap.add_argument("--fixed-time", action="store_true", help="render the identical frame every step (time = this rank's constant) instead of advancing time")
     ap.add_argument("--multi-gpu", default="virtual_frames", choices=["virtual_frames", "tiles"],
                     help="N > 1: every GPU renders its own virtual frame (N x spp, weak scaling) or a share of the tiles of one frame (strong scaling)")
@@ -257,6 +259,16 @@ def main():
     mean_img = float(bufs[(step_no[0] - 1) % F][..., :3].mean().item())   # the last (reduced) image
     # rays of a step: the mean over the last frame of every context (the count moves by a fraction of a percent with `time`)
     last = [c.stats() for c in ctxs]
+    if args.only_timed:
+        if rank == 0:
+            print(json.dumps({"only_timed": True, "workload": args.workload, "frames_in_flight": F, "steps": args.steps, "repeats": len(times),
+                              "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_step_min": round(dt_min / args.steps * 1e3, 4),
+                              "rays_per_step": int(round(float(np.mean([x["rays"] for x in last]))))}), flush=True)
+        for c in ctxs:
+            c.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
     n_rep_other = max(1, min(len(times), 5))
     # the same K steps, one frame at a time on one context: each frame complete before the next is enqueued
     times_one = timed([ctxs[0]], one_at_a_time=True, repeats=n_rep_other)

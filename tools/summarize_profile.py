@@ -42,6 +42,7 @@ def main():
     ap.add_argument("tag")
     ap.add_argument("--kernel", default="k_paths")
     ap.add_argument("--workload", default="boxes")
+    ap.add_argument("--fif-steps", type=int, default=20, help="frames of the timed region in the frames-in-flight trace")
     args = ap.parse_args()
     src = ROOT / "gpurun_out" / f"prof_{args.tag}"
     dst = ROOT / "profiles"
@@ -68,8 +69,56 @@ def main():
                     out["launch"] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
                                                        "Workgroup_Size_X", "Grid_Size_X")}
                     break
+    # Frames in flight as the bench runs them: the last `fif_steps` frames of that trace are its timed region. Per-step wall
+    # time from the device timestamps, and how much the frames overlap (kernel time summed over wall time; share of the
+    # wall time in which kernels of two or more frames run at once). The rows used are copied to profiles/ as well.
+    fif = glob.glob(str(src / "trace_fif" / "**" / "*kernel_trace.csv"), recursive=True)
+    if fif:
+        with open(fif[0]) as fh:
+            rows = [r for r in csv.DictReader(fh) if not is_stats_variant(r["Kernel_Name"])]
+        frame_rows = [r for r in rows if "k_primary" in r["Kernel_Name"] or "k_paths" in r["Kernel_Name"] or "k_chunk" in r["Kernel_Name"]]
+        paths = sorted((r for r in frame_rows if "k_paths" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+        n = min(args.fif_steps, len(paths))
+        if n:
+            t_lo = int(paths[-n]["Start_Timestamp"])
+            prim = sorted((r for r in frame_rows if "k_primary" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+            # the k_primary of the first counted frame starts before its k_paths
+            firsts = [int(r["Start_Timestamp"]) for r in prim if int(r["Start_Timestamp"]) <= t_lo]
+            t0 = max(firsts) if firsts else t_lo
+            region = sorted((r for r in frame_rows if int(r["Start_Timestamp"]) >= t0), key=lambda r: int(r["Start_Timestamp"]))
+            t1 = max(int(r["End_Timestamp"]) for r in region)
+            ev = []
+            for r in region:
+                ev.append((int(r["Start_Timestamp"]), 1))
+                ev.append((int(r["End_Timestamp"]), -1))
+            ev.sort()
+            busy = multi = 0
+            depth, last_t = 0, t0
+            for t, d in ev:
+                if depth >= 1:
+                    busy += t - last_t
+                if depth >= 2:
+                    multi += t - last_t
+                depth += d
+                last_t = t
+            ksum = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in region)
+            wall = t1 - t0
+            out["frames_in_flight_trace"] = {
+                "frames": n, "wall_ns": wall, "ms_per_step": wall / n / 1e6, "kernel_time_over_wall": ksum / wall,
+                "share_of_wall_with_two_or_more_kernels": multi / wall, "share_of_wall_with_no_kernel": 1.0 - busy / wall,
+                "mean_k_paths_ms": sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in paths[-n:]) / n / 1e6,
+                "rows": f"profiles/{args.tag}_trace_fif.csv"}
+            with open(dst / f"{args.tag}_trace_fif.csv", "w") as fh:
+                fh.write("kernel,queue,start_ns,end_ns\n")
+                for r in region:
+                    fh.write(f"{r['Kernel_Name'].split('(')[0][:40].replace(',', ';')},{r.get('Queue_Id', '')},{int(r['Start_Timestamp']) - t0},{int(r['End_Timestamp']) - t0}\n")
+        logs = glob.glob(str(src / "trace_fif.log"))
+        if logs:
+            for line in open(logs[0]):
+                if line.startswith("{") and "only_timed" in line:
+                    out["frames_in_flight_trace_bench_line"] = json.loads(line)
     counters = {}
-    for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    for sub in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
         for c, (avg, n) in read_counters(src / sub, args.kernel).items():
             counters[c] = avg
     out["counters_per_launch"] = counters
@@ -96,7 +145,9 @@ def main():
         tf = dst / "traffic.json"
         cur = json.loads(tf.read_text()) if tf.exists() else {}
         cur[args.workload] = {"hbm_bytes_per_launch": hbm["hbm_bytes_per_launch"], "tag": args.tag}
-        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"):
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES",
+                  "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32",
+                  "SQ_INST_CYCLES_VALU", "SQ_WAIT_INST_LDS", "SQ_BUSY_CYCLES"):
             if c in counters:
                 cur[args.workload][c] = counters[c]
         tf.write_text(json.dumps(cur, indent=1) + "\n")
