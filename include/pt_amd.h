@@ -240,7 +240,7 @@ int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
  * and pt_read_aux do not describe it. All calls on one GPU, from any context,
  * share the array: calls that overlap in time on one GPU race; calls on one
  * stream, or otherwise ordered, are safe. */
-#define PT_NOALLOC_MAX_PIXELS (1u << 18)   /* e.g. 512 x 512 */
+#define PT_NOALLOC_MAX_PIXELS 262144u   /* 2^18, e.g. 512 x 512 */
 int pt_render_device_noalloc(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
                              void* hip_stream);
 
@@ -251,6 +251,55 @@ int pt_render_device_noalloc(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_d
  * staging buffers play this role there). */
 int pt_host_alloc(pt_ctx* ctx, size_t bytes, void** out_ptr);
 int pt_host_free(pt_ctx* ctx, void* ptr);
+
+/* ---- several GPUs behind one handle ------------------------------------------ */
+/* No counterpart in the reference (one wgpu device, src/shader.rs:121-213). One
+ * process drives every listed GPU: the scene is replicated (uploads go to all of
+ * them), a frame is partitioned, and the one exchange step is a sum of the f32
+ * images onto the first listed GPU with RCCL (ncclReduce, all GPUs in one group
+ * call); librccl is opened at pt_multi_create, it is not a link dependency.
+ * With one device the calls are exactly their single-GPU counterparts. */
+#define PT_MULTI_MAX_DEVICES 16
+enum {
+    PT_MULTI_TILES = 0,          /* 8x8 tiles dealt round-robin to the GPUs (PtFrame.part_index/part_count);
+                                    the sum of the disjoint images is bit-identical to one GPU's frame       */
+    PT_MULTI_VIRTUAL_FRAMES = 1  /* GPU k renders the whole frame with time + k + 0.5 (k > 0): other seeds, as
+                                    successive frames of the reference have (src/raytrace.wgsl:210); the result is
+                                    sum * (1/N), N x samples per pixel per call                                 */
+};
+/* PtMultiConfig.flags */
+#define PT_MULTI_FLAG_HOST_SUM 0x1u /* diagnostic: sum the images on the host, in list order, instead of with RCCL;
+                                       a device may then be listed more than once (rehearsal on a one-GPU machine) */
+typedef struct PtMultiConfig {
+    uint32_t abi_version; /* PT_ABI_VERSION */
+    uint32_t n_devices;   /* 1..PT_MULTI_MAX_DEVICES */
+    int32_t devices[16];  /* [PT_MULTI_MAX_DEVICES] HIP ordinals; the image is returned from devices[0] */
+    uint32_t mode;        /* PT_MULTI_* */
+    uint32_t accel;       /* PT_ACCEL_* */
+    uint32_t tie_rule;    /* PT_TIE_* */
+    uint32_t flags;       /* PT_MULTI_FLAG_* */
+    uint32_t _reserved[4];
+} PtMultiConfig;
+typedef struct pt_multi pt_multi;
+int pt_multi_create(const PtMultiConfig* cfg, pt_multi** out);
+int pt_multi_destroy(pt_multi* m);
+/* Message of the most recent error (with m == NULL: of the last failed pt_multi_create). */
+const char* pt_multi_last_error(const pt_multi* m);
+/* The uploads of pt_upload_*, to every GPU. */
+int pt_multi_upload_meshes(pt_multi* m, const PtMesh* meshes, uint32_t n_meshes, const uint32_t* indices,
+                           uint32_t n_indices, const PtVertex* vertices, uint32_t n_vertices);
+int pt_multi_upload_materials(pt_multi* m, const PtMaterial* materials, uint32_t n_materials,
+                              const PtTexture* textures, uint32_t n_textures, const float* texture_data,
+                              uint32_t n_texture_data);
+int pt_multi_upload_objects(pt_multi* m, const PtObject* objects, uint32_t n_objects);
+/* pt_render over all GPUs: width*height RGBA f32 to the host, synchronous. On several GPUs frame flags are not
+ * supported and the frame's own part_index/part_count must be unset. */
+int pt_multi_render(pt_multi* m, const PtFrame* frame, void* out_rgba_host);
+/* The single-GPU context of the k-th listed device (statistics, aux planes, queries). Owned by the handle. */
+int pt_multi_context(pt_multi* m, uint32_t k, pt_ctx** out_ctx);
+/* RCCL's version number (major*10000 + minor*100 + patch) if librccl can be opened and has the entry points the
+ * library uses, else PT_ERR_UNSUPPORTED. */
+int pt_multi_rccl_version(int* version);
 
 /* ---- closest-hit query (the query.wgsl entry point on its own) -------------- */
 

@@ -77,6 +77,17 @@ class PtConfig(C.Structure):
                 ("tie_rule", C.c_uint32), ("flags", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
 
 
+PT_MULTI_MAX_DEVICES = 16
+PT_MULTI_TILES, PT_MULTI_VIRTUAL_FRAMES = 0, 1
+PT_MULTI_FLAG_HOST_SUM = 0x1
+
+
+class PtMultiConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("n_devices", C.c_uint32), ("devices", C.c_int32 * PT_MULTI_MAX_DEVICES),
+                ("mode", C.c_uint32), ("accel", C.c_uint32), ("tie_rule", C.c_uint32), ("flags", C.c_uint32),
+                ("_reserved", C.c_uint32 * 4)]
+
+
 class PtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rays_reference", C.c_uint64), ("paths", C.c_uint64),
                 ("xforms", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
@@ -100,7 +111,9 @@ assert C.sizeof(PtSettings) == 32 and C.sizeof(PtFrame) == 192 and C.sizeof(PtCo
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_upload_materials",
            "pt_upload_objects", "pt_render", "pt_render_device", "pt_query", "pt_read_aux",
            "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log", "pt_host_alloc", "pt_host_free",
-           "pt_render_device_noalloc"]
+           "pt_render_device_noalloc",
+           "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_upload_meshes", "pt_multi_upload_materials",
+           "pt_multi_upload_objects", "pt_multi_render", "pt_multi_context", "pt_multi_rccl_version"]
 
 LIB_NAME = "libpt_amd.so"
 
@@ -145,8 +158,18 @@ def load_library():
     lib.pt_debug_wave_log.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32)]
     lib.pt_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.pt_host_free.argtypes = [vp, vp]
+    lib.pt_multi_create.argtypes = [C.POINTER(PtMultiConfig), C.POINTER(vp)]
+    lib.pt_multi_destroy.argtypes = [vp]
+    lib.pt_multi_last_error.argtypes = [vp]
+    lib.pt_multi_last_error.restype = C.c_char_p
+    lib.pt_multi_upload_meshes.argtypes = [vp, vp, u32, vp, u32, vp, u32]
+    lib.pt_multi_upload_materials.argtypes = [vp, vp, u32, vp, u32, vp, u32]
+    lib.pt_multi_upload_objects.argtypes = [vp, vp, u32]
+    lib.pt_multi_render.argtypes = [vp, C.POINTER(PtFrame), vp]
+    lib.pt_multi_context.argtypes = [vp, u32, C.POINTER(vp)]
+    lib.pt_multi_rccl_version.argtypes = [C.POINTER(C.c_int)]
     for name in EXPORTS:
-        if name != "pt_last_error":
+        if name not in ("pt_last_error", "pt_multi_last_error"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -184,6 +207,75 @@ def make_frame(world_from_view, view_from_clip, width, height, *, time=0.0, boun
         f.settings.sky_color[i] = float(np.float32(sky[i]))
     f.part_index, f.part_count = int(part_index), int(part_count)
     return f
+
+
+class MultiContext:
+    """pt_multi: several GPUs behind one handle (the scene on every GPU, a frame partitioned over them, one RCCL sum)."""
+
+    def __init__(self, devices, mode: int = PT_MULTI_TILES, accel: int = PT_ACCEL_AUTO, tie_rule: int = PT_TIE_REFERENCE, flags: int = 0):
+        self._lib = load_library()
+        cfg = PtMultiConfig(abi_version=PT_ABI_VERSION, n_devices=len(devices), mode=mode, accel=accel, tie_rule=tie_rule, flags=flags)
+        for i, d in enumerate(devices):
+            cfg.devices[i] = int(d)
+        h = C.c_void_p()
+        rc = self._lib.pt_multi_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise PtError(rc, (self._lib.pt_multi_last_error(None) or b"").decode())
+        self._h = h
+        self.n = len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pt_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PtError(rc, (self._lib.pt_multi_last_error(self._h) or b"").decode())
+
+    def upload_scene(self, scene):
+        meshes = np.ascontiguousarray(scene.meshes, dtype=MESH_DT)
+        indices = np.ascontiguousarray(scene.indices, dtype=np.uint32)
+        vertices = np.ascontiguousarray(scene.vertices, dtype=VERTEX_DT)
+        self._check(self._lib.pt_multi_upload_meshes(self._h, _ptr(meshes), meshes.size, _ptr(indices), indices.size, _ptr(vertices), vertices.size))
+        materials = np.ascontiguousarray(scene.materials, dtype=MATERIAL_DT)
+        textures = np.ascontiguousarray(scene.textures, dtype=TEXTURE_DT)
+        texture_data = np.ascontiguousarray(scene.texture_data, dtype=np.float32)
+        self._check(self._lib.pt_multi_upload_materials(self._h, _ptr(materials), materials.size, _ptr(textures), textures.size,
+                                                        _ptr(texture_data), texture_data.size))
+        objects = np.ascontiguousarray(scene.objects, dtype=OBJECT_DT)
+        self._check(self._lib.pt_multi_upload_objects(self._h, _ptr(objects), objects.size))
+
+    def render(self, frame: PtFrame) -> np.ndarray:
+        dt = np.float16 if frame.flags & PT_FRAME_OUTPUT_F16 else np.float32
+        out = np.empty((frame.height, frame.width, 4), dtype=dt)
+        self._check(self._lib.pt_multi_render(self._h, C.byref(frame), _ptr(out)))
+        return out
+
+    def rays(self, k: int) -> int:
+        """Closest-hit queries GPU k executed for the last frame."""
+        h = C.c_void_p()
+        self._check(self._lib.pt_multi_context(self._h, k, C.byref(h)))
+        st = PtStats()
+        rc = self._lib.pt_get_stats(h, C.byref(st))
+        if rc != 0:
+            raise PtError(rc, (self._lib.pt_last_error(h) or b"").decode())
+        return int(st.rays)
+
+
+def rccl_version() -> int:
+    lib = load_library()
+    v = C.c_int(0)
+    rc = lib.pt_multi_rccl_version(C.byref(v))
+    if rc != 0:
+        raise PtError(rc, (lib.pt_multi_last_error(None) or b"").decode())
+    return v.value
 
 
 class Context:

@@ -1358,3 +1358,5 @@ int pt_debug_check_accel(pt_ctx* ctx, uint32_t* n_errors, uint32_t* tlas_depth, 
 }
 
 }  // extern "C"
+
+#include "pt_multi.h"

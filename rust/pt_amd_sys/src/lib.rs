@@ -164,6 +164,31 @@ pub struct pt_ctx {
     _private: [u8; 0],
 }
 
+pub const PT_MULTI_MAX_DEVICES: u32 = 16;
+pub const PT_MULTI_TILES: u32 = 0;
+pub const PT_MULTI_VIRTUAL_FRAMES: u32 = 1;
+pub const PT_MULTI_FLAG_HOST_SUM: u32 = 0x1;
+pub const PT_NOALLOC_MAX_PIXELS: u32 = 262144;
+
+/// Several GPUs behind one handle (pt_multi_*): device list, partition mode, accel and tie rule for every GPU.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PtMultiConfig {
+    pub abi_version: u32,
+    pub n_devices: u32,
+    pub devices: [i32; 16],
+    pub mode: u32,
+    pub accel: u32,
+    pub tie_rule: u32,
+    pub flags: u32,
+    pub _reserved: [u32; 4],
+}
+
+#[repr(C)]
+pub struct pt_multi {
+    _private: [u8; 0],
+}
+
 extern "C" {
     pub fn pt_create(cfg: *const PtConfig, out_ctx: *mut *mut pt_ctx) -> c_int;
     pub fn pt_destroy(ctx: *mut pt_ctx) -> c_int;
@@ -177,6 +202,17 @@ extern "C" {
     pub fn pt_render_device(ctx: *mut pt_ctx, frame: *const PtFrame, out_rgba_device: *mut c_void, hip_stream: *mut c_void) -> c_int;
     /// The same frame without device-memory allocation (frames of at most PT_NOALLOC_MAX_PIXELS pixels).
     pub fn pt_render_device_noalloc(ctx: *mut pt_ctx, frame: *const PtFrame, out_rgba_device: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn pt_multi_create(cfg: *const PtMultiConfig, out: *mut *mut pt_multi) -> c_int;
+    pub fn pt_multi_destroy(m: *mut pt_multi) -> c_int;
+    pub fn pt_multi_last_error(m: *const pt_multi) -> *const c_char;
+    pub fn pt_multi_upload_meshes(m: *mut pt_multi, meshes: *const PtMesh, n_meshes: u32, indices: *const u32, n_indices: u32,
+                                  vertices: *const PtVertex, n_vertices: u32) -> c_int;
+    pub fn pt_multi_upload_materials(m: *mut pt_multi, materials: *const PtMaterial, n_materials: u32, textures: *const PtTexture,
+                                     n_textures: u32, texture_data: *const f32, n_texture_data: u32) -> c_int;
+    pub fn pt_multi_upload_objects(m: *mut pt_multi, objects: *const PtObject, n_objects: u32) -> c_int;
+    pub fn pt_multi_render(m: *mut pt_multi, frame: *const PtFrame, out_rgba_host: *mut c_void) -> c_int;
+    pub fn pt_multi_context(m: *mut pt_multi, k: u32, out_ctx: *mut *mut pt_ctx) -> c_int;
+    pub fn pt_multi_rccl_version(version: *mut c_int) -> c_int;
     pub fn pt_host_alloc(ctx: *mut pt_ctx, bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
     pub fn pt_host_free(ctx: *mut pt_ctx, ptr: *mut c_void) -> c_int;
     pub fn pt_query(ctx: *mut pt_ctx, rays_host: *const PtRay, n_rays: u32, hits_host: *mut PtHit) -> c_int;
@@ -337,6 +373,9 @@ assert_offset!(PtHit, t, 12);
 assert_offset!(PtHit, p, 16);
 assert_offset!(PtHit, n, 28);
 assert_offset!(PtHit, uv, 40);
+assert_size!(PtMultiConfig, 104);
+assert_offset!(PtMultiConfig, devices, 8);
+assert_offset!(PtMultiConfig, mode, 72);
 
 #[cfg(test)]
 mod layout {

@@ -38,7 +38,7 @@ def test_sizes_and_offsets_match_the_header():
 
 
 def test_struct_fields_are_in_header_order():
-    for name in ("PtObject", "PtMesh", "PtVertex", "PtMaterial", "PtTexture", "PtSettings", "PtFrame", "PtConfig", "PtRay", "PtHit"):
+    for name in ("PtObject", "PtMesh", "PtVertex", "PtMaterial", "PtTexture", "PtSettings", "PtFrame", "PtConfig", "PtRay", "PtHit", "PtMultiConfig"):
         c_body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), HEADER, re.S).group(1)
         c_body = re.sub(r"/\*.*?\*/", "", c_body, flags=re.S)
         c_fields = re.findall(r"(\w+)(?:\[\d+\])?;", c_body)
@@ -50,7 +50,9 @@ def test_struct_fields_are_in_header_order():
 def test_functions_have_the_header_arity():
     decls = dict(re.findall(r"pub fn (pt_\w+)\((.*?)\) -> ", RUST, re.S))
     for fn in ("pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_upload_materials", "pt_upload_objects",
-               "pt_render", "pt_render_device", "pt_host_alloc", "pt_host_free", "pt_query", "pt_read_aux", "pt_device_info"):
+               "pt_render", "pt_render_device", "pt_render_device_noalloc", "pt_host_alloc", "pt_host_free", "pt_query", "pt_read_aux", "pt_device_info",
+               "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_upload_meshes", "pt_multi_upload_materials",
+               "pt_multi_upload_objects", "pt_multi_render", "pt_multi_context", "pt_multi_rccl_version"):
         assert fn in decls, fn
         c_args = re.search(r"^(?:int|const char\*) %s\((.*?)\);" % fn, HEADER_CODE, re.S | re.M).group(1)
         assert len(decls[fn].split(",")) == len(c_args.split(",")), fn
