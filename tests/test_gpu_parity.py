@@ -387,6 +387,34 @@ def test_cornell_4k_accel_invariance_and_oracle_crop(monkeypatch):
     assert np.array_equal(a["ray_count"][y0:y1, x0:x1], ref["ray_count"])
 
 
+@pytest.mark.parametrize("name,make,rect", [
+    ("scene_glb_textured 1080p 256 spp", lambda: scenes.scene_glb_textured(1920, 1080, 256, 10), (944, 520, 976, 544)),
+    ("cornell 3840x2160 4096 spp", lambda: scenes.cornell_4k(4096), (1900, 1060, 1924, 1076)),
+])
+def test_configurations_at_their_stated_sample_counts(name, make, rect):
+    """The two benchmark configurations whose other tests use fewer samples, once at full size: the exhaustive loop and the
+    accelerated path agree bit for bit on the whole frame, every path and ray is accounted for, and a crop agrees with the
+    CPU restatement."""
+    scene = make()
+    frame = scene.frame()
+    a = render_all(scene, frame, abi.PT_ACCEL_AUTO)
+    b = render_all(scene, frame, abi.PT_ACCEL_BRUTE)
+    assert np.array_equal(a["image"].view(np.uint32), b["image"].view(np.uint32))
+    assert np.array_equal(a["ray_count"], b["ray_count"])
+    assert np.array_equal(a["primary_flat_id"], b["primary_flat_id"])
+    assert np.isfinite(a["image"]).all() and np.all(a["image"][..., 3] == 1.0)
+    st = a["stats"]
+    assert st["paths"] == frame.width * frame.height * frame.settings.samples
+    assert st["rays_reference"] == int(a["ray_count"].astype(np.uint64).sum())
+    assert st["rays"] == st["rays_reference"] - frame.width * frame.height * (frame.settings.samples - 1)
+    x0, y0, x1, y1 = rect
+    ref = oracle_render(scene, frame, rect=rect)
+    assert (ref["primary_object"] != abi.PT_U32_MAX).any()
+    assert np.array_equal(a["image"][y0:y1, x0:x1].view(np.uint32), ref["image"].view(np.uint32))
+    assert np.array_equal(a["ray_count"][y0:y1, x0:x1], ref["ray_count"])
+    assert np.array_equal(a["primary_flat_id"][y0:y1, x0:x1], ref["primary_flat_id"])
+
+
 def test_million_triangles_tlas_vs_loop_and_oracle_crop():
     scene = scenes.instanced_boxes(83334, 1920, 1080, 1, 10)
     assert scene.n_triangles == 1000008
