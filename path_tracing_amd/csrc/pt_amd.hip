@@ -135,6 +135,7 @@ struct pt_ctx {
     uint64_t last_n_paths = ~0ull; // entries of the path list of the last frame read back
     uint32_t walk_quota = 16;     // see PathParams::walk_quota
     uint32_t blas_max_leaf = 2;   // triangles a BLAS leaf holds at most (1..PT_WIDE_MAX_LEAF); 2 measured best on the 968-triangle mesh of scene.glb
+    bool carry_acquire = true;    // see PathParams::carry_acquire (costs about 1 % of a frame; PT_AMD_CARRY_ACQUIRE=0 leaves it out)
     bool split_chunks = false;    // see PathParams::split_chunks: shorter single frames on scenes of long BVH walks, fewer frames per second when several are in flight
     bool lds_blas = true;         // object-list scenes: stage the biggest BLAS that fits in LDS (k_paths)
     uint32_t lds_per_cu = 160 * 1024;
@@ -258,6 +259,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
         if (std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = true;
+        if (const char* e = std::getenv("PT_AMD_CARRY_ACQUIRE")) ctx->carry_acquire = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_WALK_QUOTA")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->walk_quota = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_BLAS_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= (int)PT_WIDE_MAX_LEAF) ctx->blas_max_leaf = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_LDS_STACK")) { int v = std::atoi(e); if (v >= 4 && v <= (int)kMaxStackDepth) ctx->lds_stack_max = (uint32_t)v; }
@@ -1032,6 +1034,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         pp.n_sweeps = 1;
         pp.walk_quota = ctx->walk_quota;
         pp.split_chunks = ctx->split_chunks ? 1u : 0u;
+        pp.carry_acquire = ctx->carry_acquire ? 1u : 0u;
         pp.sweep_end[0] = fp.samples;
         if (pp.refill_min == 64u && pp.chunk == 64u && fp.samples >= 16u && ctx->max_sweeps > 1u) {
             uint32_t n = 0, done = 0, left = fp.samples;

@@ -69,6 +69,7 @@ struct PathParams {
     uint32_t sweep_end[8];  // slice j runs samples [sweep_end[j-1], sweep_end[j]); sweep_end[n_sweeps-1] == samples
     uint32_t split_chunks;  // 1: the most expensive chunks are handed out in parts (ChunkOrderInfo::n_split)
     uint32_t tlas_top_n;    // PT_MODE_TLAS: nodes of the TLAS (its top levels) every workgroup copies into LDS
+    uint32_t carry_acquire;    // 1: an agent-scope acquire before a chunk's parked state is read (see the sweep hand-over in k_paths)
     uint32_t* stack_overflow;  // PT_MODE_TLAS: traversal stack entries beyond the `stack_depth` kept in LDS, [entry][lane of the grid]
 };
 #define PT_MAX_SWEEPS 8
@@ -547,6 +548,14 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                                 if (lane == 0) sched[PT_SCHED_ITEM] = item;
                                 waiting = true;
                                 break;
+                            }
+                            // Consumer side of the hand-over: one relaxed poll (above), one agent-scope acquire, then the
+                            // loads. The parked state is stored and loaded with accesses that go past the non-coherent
+                            // cache levels anyway (sc0 sc1), so the acquire is a second line of defence; it can be left out
+                            // (PT_AMD_CARRY_ACQUIRE=0) to measure what it costs.
+                            if (pp.carry_acquire) {
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             }
                             asm volatile("" ::: "memory");
                         }
