@@ -1009,7 +1009,10 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
                 lb.node_base = ctx->h_blas_nodes_base[best];
                 lb.n_nodes = ctx->h_blas_n_wide[best];
                 lb.tri_first = ctx->h_meshes[best].tri_first;
-                lb.n_tris = (lds_blas_bytes(lb.n_nodes, ctx->h_meshes[best].tri_count) <= budget && !std::getenv("PT_AMD_LDS_BLAS_NODES_ONLY")) ? ctx->h_meshes[best].tri_count : 0u;
+                // its triangle records too, if two workgroups still fit on a compute unit then (two waves per SIMD hide each
+                // other's LDS and memory waits; one wave alone does not: scene.glb 17.0 against 20.2 ms per frame)
+                const size_t with_tris = lds + lds_blas_bytes(lb.n_nodes, ctx->h_meshes[best].tri_count);
+                lb.n_tris = (2 * with_tris + 2048 <= (size_t)ctx->lds_per_cu && !std::getenv("PT_AMD_LDS_BLAS_NODES_ONLY")) ? ctx->h_meshes[best].tri_count : 0u;
                 paths_mode = PT_MODE_LIST_LB;
             }
         }
