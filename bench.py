@@ -51,13 +51,17 @@ from path_tracing_amd import abi, scenes  # noqa: E402
 WORK = {"xforms": (33 + 25, 96 + 24), "box_tests": (25, 32), "tri_tests": (53, 36), "hits": (73, 60), "shades": (200, 64)}
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 (256 CU x 128 lanes x 2 flop x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0
-# What one wave64 VALU instruction costs a SIMD that holds four waves (the occupancy k_paths runs at), measured with
-# tools/micro/valu_mix.hip on this part: v_fma_f32 3.85 cycles, min/max/compare/convert/select 4.2, add/mul/mov/
-# integer add 2.4, reciprocal and square root 8.2, packed f32 4.2-4.6. 3.35 is the mean over k_paths' measured mix
-# (SQ_INSTS_VALU_* counters on boxes: 20 % FMA, 14 % MUL, 4 % ADD, 13 % INT32, 1 % transcendental, 46 % min/max/compare/
-# select/move/bit operations priced at 3.5). The 157.3 TFLOP/s peak needs a packed fused multiply-add every 4.6 cycles; a
-# stream of single FMAs tops out at 83.
-VALU_CYCLES_PER_INST = 3.35
+# What one wave64 VALU instruction costs a SIMD, measured with tools/micro/valu_mix.hip on this part at 2 to 8 waves per
+# SIMD (profiles/r02_valu_mix.txt): v_fma_f32 / v_fmac_f32 3.6-3.9 cycles; v_mul_f32, v_add_f32, v_mov_b32, v_add_u32, v_xor_b32
+# 2.3-2.4; v_min/max/max3/med3, compares, v_cndmask, conversions, v_mul_lo_u32, the v_div_* helpers, v_readlane 4.1-4.3;
+# v_rcp/v_sqrt 8.2; v_pk_fma_f32 4.4 (two fused multiply-adds: the 157.3 TFLOP/s peak is the rate of back-to-back packed
+# FMAs on full waves; a stream of single FMAs tops out at 83). One wave alone on a SIMD pays 4.8-5.2 for the 2.4- and
+# 4-cycle instructions alike. The kernel's issue time is priced per class from the SQ_INSTS_VALU_* counters of the PMC
+# passes; INT32 is a mix of 2.4- and 4.3-cycle instructions, "other" (min/max, compares, selects, conversions, moves,
+# bit operations) mostly 4.2 with the moves at 2.4.
+VALU_COST = {"SQ_INSTS_VALU_FMA_F32": 3.8, "SQ_INSTS_VALU_MUL_F32": 2.35, "SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_TRANS_F32": 8.2,
+             "SQ_INSTS_VALU_INT32": 3.3}
+VALU_COST_OTHER = 3.9
 N_SIMD = 1024
 SHADER_GHZ = 2.4
 
@@ -330,12 +334,15 @@ def main():
                 prof = json.loads(tf.read_text()).get(args.workload, {})
                 traffic = prof.get("hbm_bytes_per_launch")
                 if prof.get("SQ_INSTS_VALU"):
-                    # instruction-issue view of the same kernel: VALU wave-instructions per launch (rocprofv3 PMC pass of
-                    # tools/profile.sh) x the measured issue cost, against the kernel's duration on all SIMDs
+                    # instruction-issue view of the same kernel: VALU wave-instructions per launch by class (rocprofv3 PMC passes
+                    # of tools/profile.sh) x the measured issue cost of the class, against the kernel's duration on all SIMDs
                     n_inst = float(prof["SQ_INSTS_VALU"])
-                    issue_ms = n_inst / N_SIMD * VALU_CYCLES_PER_INST / (SHADER_GHZ * 1e9) * 1e3
-                    issue = {"valu_wave_insts_per_launch": int(n_inst), "cycles_per_inst": VALU_CYCLES_PER_INST,
-                             "issue_ms": round(issue_ms, 4), "frac_of_kernel_ms": round(issue_ms / k_ms, 4),
+                    classed = {k: float(prof[k]) for k in VALU_COST if prof.get(k)}
+                    cycles = sum(classed[k] * VALU_COST[k] for k in classed) + (n_inst - sum(classed.values())) * VALU_COST_OTHER
+                    issue_ms = cycles / N_SIMD / (SHADER_GHZ * 1e9) * 1e3
+                    issue = {"valu_wave_insts_per_launch": int(n_inst), "by_class": {k.replace("SQ_INSTS_VALU_", ""): int(v) for k, v in classed.items()},
+                             "cycles_per_inst": round(cycles / n_inst, 3),
+                             "issue_ms_at_2.4GHz": round(issue_ms, 4), "frac_of_kernel_ms": round(issue_ms / k_ms, 4),
                              "frac_of_ms_per_step": round(issue_ms / ms_per_step, 4),
                              "lanes_active_per_inst": round(float(prof["SQ_THREAD_CYCLES_VALU"]) / (float(prof["SQ_ACTIVE_INST_VALU"]) * 64.0), 4)
                              if prof.get("SQ_THREAD_CYCLES_VALU") and prof.get("SQ_ACTIVE_INST_VALU") else None,
