@@ -595,6 +595,7 @@ int rebuild_objects(pt_ctx* ctx) {
     ctx->obj_max_mesh = max_mesh;
     ctx->obj_max_mat = max_mat;
     ctx->n_objects = n;
+    const uint32_t kept[4] = {ctx->tlas_n_wide, ctx->tlas_depth, ctx->tlas_root, ctx->tlas_need};   // of the tree a refit keeps
     ctx->tlas_root = PT_NONE;
     ctx->tlas_depth = 0;
     ctx->tlas_need = 0;
@@ -631,15 +632,19 @@ int rebuild_objects(pt_ctx* ctx) {
             const size_t nb = sizeof(uint32_t) * (size_t)n;
             // Same number of objects as the tree was built for: keep the binary tree's topology (leaf order and parent
             // links) and only fit the boxes again, bottom-up. Any valid tree gives the same image; a stale topology only
-            // costs traversal steps, so a fresh build is made every kTlasMaxRefits updates. The 4-wide tree is made
-            // from the binary one either way.
-            if (ctx->allow_refit && ctx->tlas_built_n == n && ctx->tlas_refits < kTlasMaxRefits) {
+            // costs traversal steps, so a fresh build is made every kTlasMaxRefits updates. The 4-wide tree keeps its
+            // topology too: its nodes take the new boxes from the binary nodes they were made from.
+            if (ctx->allow_refit && ctx->tlas_built_n == n && ctx->tlas_refits < kTlasMaxRefits && kept[0] > 0) {
                 PT_HIP(ctx, ctx->t_arrive.ensure(nb));
                 PT_HIP(ctx, hipMemsetAsync(ctx->t_arrive.p, 0, nb, s));
                 k_fit<<<div_up(n, 256), 256, 0, s>>>(ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, ctx->d_tlas_order.as<uint32_t>(), n,
                                                      ctx->d_tlas_par_int.as<uint32_t>(), ctx->d_tlas_par_leaf.as<uint32_t>(),
                                                      ctx->t_arrive.as<uint32_t>(), ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, 0u);
                 PT_HIP(ctx, hipGetLastError());
+                k_requantise<<<div_up(kept[0], 256), 256, 0, s>>>(ctx->d_tlas_nodes.as<WNode>(), 0, kept[0], ctx->d_tlas_bnodes.as<BvhNode>(),
+                                                                  ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>());
+                PT_HIP(ctx, hipGetLastError());
+                std::memcpy(cinfo, kept, sizeof cinfo);
                 ctx->tlas_refits++;
                 refitted = true;
             } else {
@@ -655,10 +660,10 @@ int rebuild_objects(pt_ctx* ctx) {
                 PT_HIP(ctx, hipMemcpyAsync(ctx->d_tlas_par_leaf.p, ctx->t_par_leaf.p, nb, hipMemcpyDeviceToDevice, s));
                 ctx->tlas_built_n = n;
                 ctx->tlas_refits = 0;
+                rc = collapse_wide(ctx, ctx->d_tlas_bnodes.as<BvhNode>(), 0, n, false, ctx->d_tlas_nodes.as<WNode>(), 0, slot + 4);
+                if (rc != PT_OK) return rc;
+                PT_HIP(ctx, hipMemcpyAsync(cinfo, slot + 4, sizeof cinfo, hipMemcpyDeviceToHost, s));
             }
-            int rc = collapse_wide(ctx, ctx->d_tlas_bnodes.as<BvhNode>(), 0, n, false, ctx->d_tlas_nodes.as<WNode>(), 0, slot + 4);
-            if (rc != PT_OK) return rc;
-            PT_HIP(ctx, hipMemcpyAsync(cinfo, slot + 4, sizeof cinfo, hipMemcpyDeviceToHost, s));
         }
         ctx->use_tlas = true;
     }

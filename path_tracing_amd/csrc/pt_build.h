@@ -419,6 +419,44 @@ PT_DEV float slot_area(const CollapseSlot& c) {
     const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
     return dx * dy + dy * dz + dz * dx;
 }
+// Puts the boxes of a wide node's n children on the node's grid: origin, step exponents and the 8-bit corners.
+PT_DEV void wnode_set_grid(WNode& N, const CollapseSlot* sl, int n) {
+    float big = 0.0f;
+    for (int j = 0; j < n; ++j)
+        for (int a = 0; a < 3; ++a) big = fmaxf(big, fmaxf(fabsf(sl[j].lo[a]), fabsf(sl[j].hi[a])));
+    const float pad = fminf(big, 1.7e38f) * 0x1p-20f;
+    uint32_t exps = 0;
+    for (int a = 0; a < 3; ++a) {
+        float mn = 3.0e38f, mx = -3.0e38f;
+        for (int j = 0; j < n; ++j) { mn = fminf(mn, sl[j].lo[a] - pad); mx = fmaxf(mx, sl[j].hi[a] + pad); }
+        mn = fmaxf(mn, -1.7e38f);   // ("unbounded" boxes of objects with non-finite transforms: keep the extent finite)
+        mx = fminf(mx, 1.7e38f);
+        const float o = mn;
+        const float t = (mx - o) * (1.0f / 253.0f);
+        int e = -100;
+        if (t > 0.0f) { (void)frexpf(t, &e); }   // t = m * 2^e, m in [0.5, 1): 2^e >= t
+        e = min(max(e, -100), 126);
+        const float step = ldexpf(1.0f, e), inv_step = ldexpf(1.0f, -e);
+        uint32_t wlo = 0, whi = 0;
+        for (int j = 0; j < 4; ++j) {
+            int ql = 255, qh = 0;   // empty slot: inverted
+            if (j < n) {
+                const float lo = fmaxf(sl[j].lo[a] - pad, -1.7e38f), hi = fminf(sl[j].hi[a] + pad, 1.7e38f);
+                ql = (int)fminf(fmaxf(floorf((lo - o) * inv_step), 0.0f), 255.0f);
+                while (ql > 0 && fmaf((float)ql, step, o) > lo) --ql;
+                qh = (int)fminf(fmaxf(ceilf((hi - o) * inv_step), 0.0f), 255.0f);
+                while (qh < 255 && fmaf((float)qh, step, o) < hi) ++qh;
+            }
+            wlo |= (uint32_t)ql << (8 * j);
+            whi |= (uint32_t)qh << (8 * j);
+        }
+        N.origin[a] = o;
+        N.qlo[a] = wlo;
+        N.qhi[a] = whi;
+        exps |= (uint32_t)(e + 127) << (8 * a);
+    }
+    N.exps = exps;
+}
 __global__ __launch_bounds__(1024) void k_collapse(const BvhNode* __restrict__ bnodes, uint32_t bnode_base, uint32_t n_prims,
                                                    const uint2* __restrict__ ranges, uint32_t max_leaf,
                                                    WNode* __restrict__ wnodes, uint32_t wnode_base, uint2* __restrict__ work,
@@ -497,42 +535,7 @@ __global__ __launch_bounds__(1024) void k_collapse(const BvhNode* __restrict__ b
                     ++r;
                 }
             }
-            // the grid
-            float big = 0.0f;
-            for (int j = 0; j < n; ++j)
-                for (int a = 0; a < 3; ++a) big = fmaxf(big, fmaxf(fabsf(sl[j].lo[a]), fabsf(sl[j].hi[a])));
-            const float pad = fminf(big, 1.7e38f) * 0x1p-20f;
-            uint32_t exps = 0;
-            for (int a = 0; a < 3; ++a) {
-                float mn = 3.0e38f, mx = -3.0e38f;
-                for (int j = 0; j < n; ++j) { mn = fminf(mn, sl[j].lo[a] - pad); mx = fmaxf(mx, sl[j].hi[a] + pad); }
-                mn = fmaxf(mn, -1.7e38f);   // ("unbounded" boxes of objects with non-finite transforms: keep the extent finite)
-                mx = fminf(mx, 1.7e38f);
-                const float o = mn;
-                const float t = (mx - o) * (1.0f / 253.0f);
-                int e = -100;
-                if (t > 0.0f) { (void)frexpf(t, &e); }   // t = m * 2^e, m in [0.5, 1): 2^e >= t
-                e = min(max(e, -100), 126);
-                const float step = ldexpf(1.0f, e), inv_step = ldexpf(1.0f, -e);
-                uint32_t wlo = 0, whi = 0;
-                for (int j = 0; j < 4; ++j) {
-                    int ql = 255, qh = 0;   // empty slot: inverted
-                    if (j < n) {
-                        const float lo = fmaxf(sl[j].lo[a] - pad, -1.7e38f), hi = fminf(sl[j].hi[a] + pad, 1.7e38f);
-                        ql = (int)fminf(fmaxf(floorf((lo - o) * inv_step), 0.0f), 255.0f);
-                        while (ql > 0 && fmaf((float)ql, step, o) > lo) --ql;
-                        qh = (int)fminf(fmaxf(ceilf((hi - o) * inv_step), 0.0f), 255.0f);
-                        while (qh < 255 && fmaf((float)qh, step, o) < hi) ++qh;
-                    }
-                    wlo |= (uint32_t)ql << (8 * j);
-                    whi |= (uint32_t)qh << (8 * j);
-                }
-                N.origin[a] = o;
-                N.qlo[a] = wlo;
-                N.qhi[a] = whi;
-                exps |= (uint32_t)(e + 127) << (8 * a);
-            }
-            N.exps = exps;
+            wnode_set_grid(N, sl, n);
             N._pad[0] = item.x;   // (build bookkeeping: the binary node this one started from)
             N._pad[1] = held;
             wnodes[w] = N;
@@ -547,6 +550,37 @@ __global__ __launch_bounds__(1024) void k_collapse(const BvhNode* __restrict__ b
         info[2] = wnode_base;
         info[3] = s_need;
     }
+}
+
+// Refit of a TLAS's wide tree after k_fit has fitted the binary tree it was made from again: the topology (children,
+// numbering, stack need) stays, every node takes its children's new boxes -- from the binary node a child node started
+// from, or from the object's box for a leaf -- and puts them on a new grid. One thread per node, no order between them.
+__global__ void k_requantise(WNode* __restrict__ wnodes, uint32_t wnode_base, uint32_t n_nodes, const BvhNode* __restrict__ bnodes,
+                             const float4* __restrict__ box_lo, const float4* __restrict__ box_hi) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    WNode N = wnodes[i];
+    CollapseSlot sl[4];
+    int n = 0;
+    for (int j = 0; j < 4; ++j) {   // (children fill the slots from 0 up)
+        const uint32_t ref = N.child[j];
+        if (ref == PT_NONE) break;
+        sl[j].ref = ref;
+        if (ref & PT_LEAF_BIT) {
+            const float4 a = box_lo[ref & ~PT_LEAF_BIT], b = box_hi[ref & ~PT_LEAF_BIT];
+            sl[j].lo[0] = a.x; sl[j].lo[1] = a.y; sl[j].lo[2] = a.z;
+            sl[j].hi[0] = b.x; sl[j].hi[1] = b.y; sl[j].hi[2] = b.z;
+        } else {
+            const BvhNode B = bnodes[wnodes[ref - wnode_base]._pad[0]];
+            sl[j].lo[0] = fminf(B.lo_l.x, B.lo_r.x); sl[j].lo[1] = fminf(B.lo_l.y, B.lo_r.y); sl[j].lo[2] = fminf(B.lo_l.z, B.lo_r.z);
+            sl[j].hi[0] = fmaxf(B.hi_l.x, B.hi_r.x); sl[j].hi[1] = fmaxf(B.hi_l.y, B.hi_r.y); sl[j].hi[2] = fmaxf(B.hi_l.z, B.hi_r.z);
+        }
+        n = j + 1;
+    }
+    wnode_set_grid(N, sl, n);
+    WNode* W = &wnodes[i];   // (only the box words: another thread may be reading this node's bookkeeping word)
+    for (int a = 0; a < 3; ++a) { W->origin[a] = N.origin[a]; W->qlo[a] = N.qlo[a]; W->qhi[a] = N.qhi[a]; }
+    W->exps = N.exps;
 }
 
 // Checks a wide tree: every child box, decoded the way the comment of WNode says, must enclose what lies below it (the

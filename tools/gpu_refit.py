@@ -10,9 +10,13 @@ sc = scenes.instanced_boxes(83334, 1920, 1080, 1, 10)
 with abi.Context() as ctx:
     ctx.upload_scene(sc)
     fr = sc.frame()
+    ctx.render(fr)
+    print(f"first upload (fresh build): device {ctx.stats()['build_ms']:.3f} ms")
+    objs = sc.objects.copy()
     for k in range(4):
+        objs["local_to_world"][k * 1000, 13] += 0.25   # one object moves: an identical array would be a no-op
         t0 = time.perf_counter()
-        ctx.upload_objects(sc.objects)
+        ctx.upload_objects(objs)
         wall = (time.perf_counter() - t0) * 1e3
         ctx.render(fr)
         st = ctx.stats()
