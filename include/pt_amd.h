@@ -270,6 +270,8 @@ enum {
 /* PtMultiConfig.flags */
 #define PT_MULTI_FLAG_HOST_SUM 0x1u /* diagnostic: sum the images on the host, in list order, instead of with RCCL;
                                        a device may then be listed more than once (rehearsal on a one-GPU machine) */
+#define PT_MULTI_FLAG_FORCE_COLLECTIVE 0x2u /* diagnostic: a one-device handle also goes through RCCL (a communicator of
+                                               one rank, the same ncclReduce call), instead of being plain pt_render */
 typedef struct PtMultiConfig {
     uint32_t abi_version; /* PT_ABI_VERSION */
     uint32_t n_devices;   /* 1..PT_MULTI_MAX_DEVICES */

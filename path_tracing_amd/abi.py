@@ -80,6 +80,7 @@ class PtConfig(C.Structure):
 PT_MULTI_MAX_DEVICES = 16
 PT_MULTI_TILES, PT_MULTI_VIRTUAL_FRAMES = 0, 1
 PT_MULTI_FLAG_HOST_SUM = 0x1
+PT_MULTI_FLAG_FORCE_COLLECTIVE = 0x2
 
 
 class PtMultiConfig(C.Structure):

@@ -185,7 +185,7 @@ int pt_multi_create(const PtMultiConfig* cfg, pt_multi** out) {
                 return mfail(nullptr, PT_ERR_DEVICE, msg);
             }
         }
-        if (m->n > 1 && !host_sum) {
+        if ((m->n > 1 || (cfg->flags & PT_MULTI_FLAG_FORCE_COLLECTIVE)) && !host_sum) {
             if (!rccl_load()) {
                 const std::string msg = "pt_multi_create: " + g_rccl.error;
                 pt_multi_destroy(m);
@@ -248,7 +248,7 @@ int pt_multi_render(pt_multi* m, const PtFrame* frame, void* out_rgba_host) {
     if (!m) return PT_ERR_INVALID_ARGUMENT;
     try {
         if (!frame || !out_rgba_host) return mfail(m, PT_ERR_INVALID_ARGUMENT, "pt_multi_render: null argument");
-        if (m->n == 1) {   // one GPU: exactly pt_render
+        if (m->n == 1 && !(m->cfg.flags & PT_MULTI_FLAG_FORCE_COLLECTIVE)) {   // one GPU: exactly pt_render
             const int rc = pt_render(m->ctx[0], frame, out_rgba_host);
             return rc == PT_OK ? PT_OK : mfail_ctx(m, rc, 0);
         }

@@ -168,6 +168,7 @@ pub const PT_MULTI_MAX_DEVICES: u32 = 16;
 pub const PT_MULTI_TILES: u32 = 0;
 pub const PT_MULTI_VIRTUAL_FRAMES: u32 = 1;
 pub const PT_MULTI_FLAG_HOST_SUM: u32 = 0x1;
+pub const PT_MULTI_FLAG_FORCE_COLLECTIVE: u32 = 0x2;
 pub const PT_NOALLOC_MAX_PIXELS: u32 = 262144;
 
 /// Several GPUs behind one handle (pt_multi_*): device list, partition mode, accel and tie rule for every GPU.

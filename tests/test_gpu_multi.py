@@ -33,6 +33,22 @@ def test_rccl_can_be_opened():
     assert abi.rccl_version() >= 20000   # RCCL reports an NCCL 2.x version number
 
 
+@pytest.mark.parametrize("mode", [abi.PT_MULTI_TILES, abi.PT_MULTI_VIRTUAL_FRAMES])
+def test_one_rank_through_the_collective(mode):
+    """The RCCL leg itself on the one GPU there is: a communicator of one rank, the grouped ncclReduce onto rank 0 behind
+    the frame on its stream, the scale and the copy. The image must be pt_render's, twice in a row."""
+    scene = scenes.cornell_box(100, 61, 4, 10)
+    frame = scene.frame(time=0.5)
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        want = ctx.render(frame)
+    with abi.MultiContext([0], mode=mode, flags=abi.PT_MULTI_FLAG_FORCE_COLLECTIVE) as m:
+        m.upload_scene(scene)
+        for _ in range(2):
+            got = m.render(frame)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("n", [2, 3])
 def test_tiles_over_several_handles_assemble_the_frame(n):
     scene = scenes.cornell_box(100, 61, 4, 10)     # ragged size: partial tiles
