@@ -675,6 +675,27 @@ def test_object_update_refits_tlas_with_identical_results():
         assert not ctx.stats()["accel_used"] & 4
 
 
+def test_many_refits_then_a_fresh_build():
+    """Refits keep a topology that fits the moved objects worse and worse, so every 16th update builds afresh; the trees
+    must be valid after every update and the image that of a fresh context."""
+    a = scenes.instanced_boxes(n_objects=400, width=64, height=48, samples=2, extent=5.0)
+    b = scenes.instanced_boxes(n_objects=400, width=64, height=48, samples=2, extent=5.0, seed=99)
+    frame = a.frame()
+    want = {0: render_all(a, frame)["image"], 1: None}
+    with abi.Context() as ctx:
+        ctx.upload_scene(a)
+        ctx.render(frame)
+        flags = []
+        for k in range(18):
+            ctx.upload_objects((b if k % 2 == 0 else a).objects)
+            assert ctx.check_accel()["errors"] == 0, k
+            ctx.render(frame)
+            flags.append(bool(ctx.stats()["accel_used"] & 4))
+        assert flags == [True] * 15 + [False] + [True] * 2
+        img = ctx.render(frame)     # the 18th upload was scene a's objects (materials of a were never replaced)
+    assert np.array_equal(img.view(np.uint32), want[0].view(np.uint32))
+
+
 def test_reupload_order_independent():
     scene = scenes.boxes(64, 36, 2, 4)
     ref = render_all(scene, scene.frame())
