@@ -25,6 +25,7 @@ namespace {
 constexpr uint32_t kBlasMinTris = 16;   // PT_ACCEL_AUTO: meshes with more triangles than this get a BLAS
 constexpr uint32_t kTlasMinObjects = 12; // PT_ACCEL_AUTO: scenes with more objects than this get a TLAS
 constexpr uint32_t kMaxStackDepth = 96;
+constexpr uint32_t kCollapseOneGroupMax = 4096;   // primitives up to which one workgroup makes the whole wide tree
 constexpr uint32_t kTlasMaxRefits = 15;  // object uploads that may refit the TLAS before it is built afresh  // LDS: 4 waves * depth * 256 B per workgroup
 
 thread_local std::string g_create_error;
@@ -104,7 +105,7 @@ struct pt_ctx {
     DevBuf d_materials, d_textures, d_texdata;
     // scratch for uploads / builds
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
-        t_bounds, t_info, t_errors, t_ranges, t_work, t_tris_tmp;
+        t_bounds, t_info, t_errors, t_ranges, t_work, t_tris_tmp, t_cstate;
     // frame outputs
     DevBuf d_stack_overflow, d_out, d_out16, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_rays, d_hits, d_paths, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
 
@@ -219,11 +220,30 @@ int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t
 
 // The 4-wide tree the rays walk, from a binary tree of n - 1 nodes over n primitives (k_collapse). info (device):
 // {nodes, levels, root reference, stack entries a walk can need}.
+// binary_depth (device): the word k_fit left the binary tree's depth in; a wide tree has at most that many levels.
 int collapse_wide(pt_ctx* ctx, const BvhNode* bnodes, uint32_t bnode_base, uint32_t n, bool blas, WNode* wnodes, uint32_t wnode_base,
-                  uint32_t* info) {
+                  uint32_t* info, const uint32_t* binary_depth) {
+    hipStream_t s = ctx->stream;
     PT_HIP(ctx, ctx->t_work.ensure(sizeof(uint2) * (size_t)std::max<uint32_t>(n, 1)));
-    k_collapse<<<1, 1024, 0, ctx->stream>>>(bnodes, bnode_base, n, blas ? ctx->t_ranges.as<uint2>() : nullptr, ctx->blas_max_leaf, wnodes, wnode_base,
-                                            ctx->t_work.as<uint2>(), info);
+    const uint2* ranges = blas ? ctx->t_ranges.as<uint2>() : nullptr;
+    if (n <= kCollapseOneGroupMax) {
+        k_collapse<<<1, 1024, 0, s>>>(bnodes, bnode_base, n, ranges, ctx->blas_max_leaf, wnodes, wnode_base, ctx->t_work.as<uint2>(), info);
+        PT_HIP(ctx, hipGetLastError());
+        return PT_OK;
+    }
+    // one launch per level; the number of levels is known only on the device, so as many launches as the binary tree is deep
+    uint32_t depth = 0;
+    PT_HIP(ctx, hipMemcpyAsync(&depth, binary_depth, sizeof depth, hipMemcpyDeviceToHost, s));
+    PT_HIP(ctx, hipStreamSynchronize(s));
+    const uint32_t launches = depth + 1u;
+    const size_t state_bytes = sizeof(uint32_t) * (4 + 2 * ((size_t)launches + 2));
+    PT_HIP(ctx, ctx->t_cstate.ensure(state_bytes));
+    PT_HIP(ctx, hipMemsetAsync(ctx->t_cstate.p, 0, state_bytes, s));
+    k_collapse_begin<<<1, 1, 0, s>>>(ctx->t_work.as<uint2>(), ctx->t_cstate.as<uint32_t>());
+    const uint32_t groups = std::min<uint32_t>(2u * ctx->n_cus, div_up(n, 256));
+    for (uint32_t level = 0; level < launches; ++level)
+        k_collapse_level<<<groups, 256, 0, s>>>(bnodes, bnode_base, ranges, ctx->blas_max_leaf, wnodes, wnode_base, ctx->t_work.as<uint2>(),
+                                                ctx->t_cstate.as<uint32_t>(), level, info);
     PT_HIP(ctx, hipGetLastError());
     return PT_OK;
 }
@@ -320,7 +340,7 @@ int pt_destroy(pt_ctx* ctx) {
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
                       &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_out16, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
                       &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log,
-                      &ctx->d_stack_overflow, &ctx->d_tri_ids, &ctx->d_blas_bnodes, &ctx->d_blas_order, &ctx->d_obj_l2w, &ctx->d_tlas_bnodes, &ctx->t_ranges, &ctx->t_work, &ctx->t_tris_tmp};
+                      &ctx->d_stack_overflow, &ctx->d_tri_ids, &ctx->d_blas_bnodes, &ctx->d_blas_order, &ctx->d_obj_l2w, &ctx->d_tlas_bnodes, &ctx->t_ranges, &ctx->t_work, &ctx->t_tris_tmp, &ctx->t_cstate};
     for (DevBuf* b : bufs) b->release();
     for (void* p : ctx->host_allocs) (void)hipHostFree(p);
     for (FrameSlot& sl : ctx->slot) {
@@ -452,7 +472,7 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
             PT_HIP(ctx, hipGetLastError());
             PT_HIP(ctx, hipMemcpyAsync(ctx->d_tris.as<DTri>() + first, ctx->t_tris_tmp.p, sizeof(DTri) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
             PT_HIP(ctx, hipMemcpyAsync(ctx->d_blas_order.as<uint32_t>() + first, ctx->t_vals0.p, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
-            rc = collapse_wide(ctx, bn, node_base[m], cnt, true, ctx->d_blas_nodes.as<WNode>() + node_base[m], node_base[m], info + 4);
+            rc = collapse_wide(ctx, bn, node_base[m], cnt, true, ctx->d_blas_nodes.as<WNode>() + node_base[m], node_base[m], info + 4, info);
             if (rc != PT_OK) return rc;
         }
         std::vector<uint32_t> infos(8 * (size_t)(n_meshes + 1), 0);
@@ -660,7 +680,7 @@ int rebuild_objects(pt_ctx* ctx) {
                 PT_HIP(ctx, hipMemcpyAsync(ctx->d_tlas_par_leaf.p, ctx->t_par_leaf.p, nb, hipMemcpyDeviceToDevice, s));
                 ctx->tlas_built_n = n;
                 ctx->tlas_refits = 0;
-                rc = collapse_wide(ctx, ctx->d_tlas_bnodes.as<BvhNode>(), 0, n, false, ctx->d_tlas_nodes.as<WNode>(), 0, slot + 4);
+                rc = collapse_wide(ctx, ctx->d_tlas_bnodes.as<BvhNode>(), 0, n, false, ctx->d_tlas_nodes.as<WNode>(), 0, slot + 4, slot);
                 if (rc != PT_OK) return rc;
                 PT_HIP(ctx, hipMemcpyAsync(cinfo, slot + 4, sizeof cinfo, hipMemcpyDeviceToHost, s));
             }

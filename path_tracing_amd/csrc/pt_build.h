@@ -457,6 +457,72 @@ PT_DEV void wnode_set_grid(WNode& N, const CollapseSlot* sl, int n) {
     }
     N.exps = exps;
 }
+// One wide node: work item `item` of node number w. Children that become nodes get consecutive numbers from *next;
+// *need collects the largest number of stack entries held.
+PT_DEV void collapse_one(uint32_t w, const uint2 item, const BvhNode* __restrict__ bnodes, uint32_t bnode_base,
+                         const uint2* __restrict__ ranges, uint32_t max_leaf, WNode* __restrict__ wnodes, uint32_t wnode_base,
+                         uint2* __restrict__ work, uint32_t* next, uint32_t* need) {
+    auto count_below = [&](uint32_t ref) -> uint32_t {   // primitives below a binary child reference
+        if (ref & PT_LEAF_BIT) return 1u;
+        if (!ranges) return 0xFFFFFFFFu;
+        const uint2 r = ranges[ref - bnode_base];
+        return r.y - r.x + 1u;
+    };
+    CollapseSlot sl[4];
+    int n = 2;
+    {
+        const BvhNode B = bnodes[item.x];
+        sl[0].ref = __float_as_uint(B.lo_l.w); sl[0].lo[0] = B.lo_l.x; sl[0].lo[1] = B.lo_l.y; sl[0].lo[2] = B.lo_l.z;
+        sl[0].hi[0] = B.hi_l.x; sl[0].hi[1] = B.hi_l.y; sl[0].hi[2] = B.hi_l.z;
+        sl[1].ref = __float_as_uint(B.lo_r.w); sl[1].lo[0] = B.lo_r.x; sl[1].lo[1] = B.lo_r.y; sl[1].lo[2] = B.lo_r.z;
+        sl[1].hi[0] = B.hi_r.x; sl[1].hi[1] = B.hi_r.y; sl[1].hi[2] = B.hi_r.z;
+    }
+    while (n < 4) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int j = 0; j < n; ++j) {
+            if (sl[j].ref & PT_LEAF_BIT) continue;
+            if (ranges && count_below(sl[j].ref) <= max_leaf) continue;
+            const float a = slot_area(sl[j]);
+            if (!(a <= best_area)) { best_area = a; best = j; }   // (a NaN area is opened too)
+        }
+        if (best < 0) break;
+        const BvhNode B = bnodes[sl[best].ref - bnode_base];
+        sl[best].ref = __float_as_uint(B.lo_l.w); sl[best].lo[0] = B.lo_l.x; sl[best].lo[1] = B.lo_l.y; sl[best].lo[2] = B.lo_l.z;
+        sl[best].hi[0] = B.hi_l.x; sl[best].hi[1] = B.hi_l.y; sl[best].hi[2] = B.hi_l.z;
+        sl[n].ref = __float_as_uint(B.lo_r.w); sl[n].lo[0] = B.lo_r.x; sl[n].lo[1] = B.lo_r.y; sl[n].lo[2] = B.lo_r.z;
+        sl[n].hi[0] = B.hi_r.x; sl[n].hi[1] = B.hi_r.y; sl[n].hi[2] = B.hi_r.z;
+        ++n;
+    }
+    // children: leaves keep / get their leaf reference, the others become wide nodes of the next level
+    uint32_t n_inner = 0;
+    for (int j = 0; j < n; ++j)
+        if (!(sl[j].ref & PT_LEAF_BIT) && !(ranges && count_below(sl[j].ref) <= max_leaf)) ++n_inner;
+    const uint32_t base = n_inner ? atomicAdd(next, n_inner) : 0u;
+    const uint32_t held = item.y + (uint32_t)n - 1u;   // entries on the stack while a walk is below this node
+    atomicMax(need, held);
+    WNode N;
+    uint32_t r = 0;
+    for (int j = 0; j < 4; ++j) {
+        if (j >= n) { N.child[j] = PT_NONE; continue; }
+        const uint32_t ref = sl[j].ref;
+        if (ref & PT_LEAF_BIT) {
+            N.child[j] = ref;   // TLAS: the object; BLAS: one triangle at this position (count - 1 = 0)
+        } else if (ranges && count_below(ref) <= max_leaf) {
+            const uint2 rg = ranges[ref - bnode_base];
+            N.child[j] = PT_LEAF_BIT | ((rg.y - rg.x) << PT_WLEAF_COUNT_SHIFT) | rg.x;
+        } else {
+            work[base + r] = make_uint2(ref - bnode_base, held);
+            N.child[j] = wnode_base + base + r;
+            ++r;
+        }
+    }
+    wnode_set_grid(N, sl, n);
+    N._pad[0] = item.x;   // (build bookkeeping: the binary node this one started from)
+    N._pad[1] = held;
+    wnodes[w] = N;
+}
+// Small trees: one workgroup does all levels.
 __global__ __launch_bounds__(1024) void k_collapse(const BvhNode* __restrict__ bnodes, uint32_t bnode_base, uint32_t n_prims,
                                                    const uint2* __restrict__ ranges, uint32_t max_leaf,
                                                    WNode* __restrict__ wnodes, uint32_t wnode_base, uint2* __restrict__ work,
@@ -475,71 +541,11 @@ __global__ __launch_bounds__(1024) void k_collapse(const BvhNode* __restrict__ b
         s_begin = 0; s_end = 1; s_next = 1; s_need = 0; s_levels = 0;
     }
     __syncthreads();
-    auto count_below = [&](uint32_t ref) -> uint32_t {   // primitives below a binary child reference
-        if (ref & PT_LEAF_BIT) return 1u;
-        if (!ranges) return 0xFFFFFFFFu;
-        const uint2 r = ranges[ref - bnode_base];
-        return r.y - r.x + 1u;
-    };
     for (;;) {
         const uint32_t begin = s_begin, end = s_end;
         if (begin == end) break;
-        for (uint32_t w = begin + tid; w < end; w += blockDim.x) {
-            const uint2 item = work[w];
-            CollapseSlot sl[4];
-            int n = 2;
-            {
-                const BvhNode B = bnodes[item.x];
-                sl[0].ref = __float_as_uint(B.lo_l.w); sl[0].lo[0] = B.lo_l.x; sl[0].lo[1] = B.lo_l.y; sl[0].lo[2] = B.lo_l.z;
-                sl[0].hi[0] = B.hi_l.x; sl[0].hi[1] = B.hi_l.y; sl[0].hi[2] = B.hi_l.z;
-                sl[1].ref = __float_as_uint(B.lo_r.w); sl[1].lo[0] = B.lo_r.x; sl[1].lo[1] = B.lo_r.y; sl[1].lo[2] = B.lo_r.z;
-                sl[1].hi[0] = B.hi_r.x; sl[1].hi[1] = B.hi_r.y; sl[1].hi[2] = B.hi_r.z;
-            }
-            while (n < 4) {
-                int best = -1;
-                float best_area = -1.0f;
-                for (int j = 0; j < n; ++j) {
-                    if (sl[j].ref & PT_LEAF_BIT) continue;
-                    if (ranges && count_below(sl[j].ref) <= max_leaf) continue;
-                    const float a = slot_area(sl[j]);
-                    if (!(a <= best_area)) { best_area = a; best = j; }   // (a NaN area is opened too)
-                }
-                if (best < 0) break;
-                const BvhNode B = bnodes[sl[best].ref - bnode_base];
-                sl[best].ref = __float_as_uint(B.lo_l.w); sl[best].lo[0] = B.lo_l.x; sl[best].lo[1] = B.lo_l.y; sl[best].lo[2] = B.lo_l.z;
-                sl[best].hi[0] = B.hi_l.x; sl[best].hi[1] = B.hi_l.y; sl[best].hi[2] = B.hi_l.z;
-                sl[n].ref = __float_as_uint(B.lo_r.w); sl[n].lo[0] = B.lo_r.x; sl[n].lo[1] = B.lo_r.y; sl[n].lo[2] = B.lo_r.z;
-                sl[n].hi[0] = B.hi_r.x; sl[n].hi[1] = B.hi_r.y; sl[n].hi[2] = B.hi_r.z;
-                ++n;
-            }
-            // children: leaves keep / get their leaf reference, the others become wide nodes of the next level
-            uint32_t n_inner = 0;
-            for (int j = 0; j < n; ++j)
-                if (!(sl[j].ref & PT_LEAF_BIT) && !(ranges && count_below(sl[j].ref) <= max_leaf)) ++n_inner;
-            const uint32_t base = n_inner ? atomicAdd(&s_next, n_inner) : 0u;
-            const uint32_t held = item.y + (uint32_t)n - 1u;   // entries on the stack while a walk is below this node
-            atomicMax(&s_need, held);
-            WNode N;
-            uint32_t r = 0;
-            for (int j = 0; j < 4; ++j) {
-                if (j >= n) { N.child[j] = PT_NONE; continue; }
-                const uint32_t ref = sl[j].ref;
-                if (ref & PT_LEAF_BIT) {
-                    N.child[j] = ref;   // TLAS: the object; BLAS: one triangle at this position (count - 1 = 0)
-                } else if (ranges && count_below(ref) <= max_leaf) {
-                    const uint2 rg = ranges[ref - bnode_base];
-                    N.child[j] = PT_LEAF_BIT | ((rg.y - rg.x) << PT_WLEAF_COUNT_SHIFT) | rg.x;
-                } else {
-                    work[base + r] = make_uint2(ref - bnode_base, held);
-                    N.child[j] = wnode_base + base + r;
-                    ++r;
-                }
-            }
-            wnode_set_grid(N, sl, n);
-            N._pad[0] = item.x;   // (build bookkeeping: the binary node this one started from)
-            N._pad[1] = held;
-            wnodes[w] = N;
-        }
+        for (uint32_t w = begin + tid; w < end; w += blockDim.x)
+            collapse_one(w, work[w], bnodes, bnode_base, ranges, max_leaf, wnodes, wnode_base, work, &s_next, &s_need);
         __syncthreads();
         if (tid == 0) { s_begin = end; s_end = s_next; s_levels++; }
         __syncthreads();
@@ -549,6 +555,42 @@ __global__ __launch_bounds__(1024) void k_collapse(const BvhNode* __restrict__ b
         info[1] = s_levels;
         info[2] = wnode_base;
         info[3] = s_need;
+    }
+}
+// Large trees: one launch per level over many workgroups. state: [0] next free node number, [1] stack need, [2] workgroups
+// that have finished the level, [3] -, [4 + 2 L], [5 + 2 L] first and end node of level L. The workgroup that finishes a
+// level last sets up the next level's range and brings info[] up to date, so that after the last launch info[] is what
+// k_collapse would have left (launches beyond the tree's last level find an empty range and do nothing).
+__global__ void k_collapse_begin(uint2* __restrict__ work, uint32_t* __restrict__ state) {
+    work[0] = make_uint2(0u, 0u);
+    state[0] = 1u;
+    state[4] = 0u;
+    state[5] = 1u;
+}
+__global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restrict__ bnodes, uint32_t bnode_base, const uint2* __restrict__ ranges,
+                                                        uint32_t max_leaf, WNode* __restrict__ wnodes, uint32_t wnode_base,
+                                                        uint2* __restrict__ work, uint32_t* __restrict__ state, uint32_t level,
+                                                        uint32_t* __restrict__ info) {
+    const uint32_t begin = state[4 + 2 * level], end = state[5 + 2 * level];   // written before this launch began
+    if (begin == end) return;
+    for (uint32_t w = begin + blockIdx.x * blockDim.x + threadIdx.x; w < end; w += gridDim.x * blockDim.x)
+        collapse_one(w, work[w], bnodes, bnode_base, ranges, max_leaf, wnodes, wnode_base, work, &state[0], &state[1]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t done = __hip_atomic_fetch_add(&state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint32_t next = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t need = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            state[4 + 2 * (level + 1u)] = end;
+            state[5 + 2 * (level + 1u)] = next;
+            __hip_atomic_store(&state[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            info[0] = next;
+            info[1] = level + 1u;
+            info[2] = wnode_base;
+            info[3] = need;
+        }
     }
 }
 

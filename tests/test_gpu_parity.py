@@ -675,6 +675,47 @@ def test_object_update_refits_tlas_with_identical_results():
         assert not ctx.stats()["accel_used"] & 4
 
 
+def test_mesh_with_a_deep_blas_against_the_loop_and_the_oracle():
+    """A mesh of 20,000 triangles (a bumpy sphere): its wide BLAS is made level by level over many workgroups, not by the
+    one-workgroup kernel the small meshes get. Tree checks, the whole frame against the exhaustive loop, a crop against
+    the CPU restatement."""
+    nu, nv = 100, 100
+    u = np.linspace(0.0, 2.0 * np.pi, nu + 1)
+    v = np.linspace(0.02, np.pi - 0.02, nv + 1)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    r = 1.0 + 0.08 * np.sin(7.0 * uu) * np.sin(5.0 * vv)
+    pos = np.stack([r * np.sin(vv) * np.cos(uu), r * np.cos(vv), r * np.sin(vv) * np.sin(uu)], axis=-1).reshape(-1, 3)
+    nrm = pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    uv = np.stack([uu / (2.0 * np.pi), vv / np.pi], axis=-1).reshape(-1, 2)
+    idx = []
+    for i in range(nu):
+        for j in range(nv):
+            a, b, c, d = i * (nv + 1) + j, (i + 1) * (nv + 1) + j, (i + 1) * (nv + 1) + j + 1, i * (nv + 1) + j + 1
+            idx += [a, d, b, b, d, c]   # counter-clockwise seen from outside
+    b = scenes.SceneBuilder()
+    mesh = b.add_mesh(pos, nrm, uv, np.array(idx))
+    floor = b.add_mesh(*scenes.cube_mesh(1.0))
+    b.add_object(mesh, b.add_material(albedo=(0.8, 0.6, 0.3), roughness=0.4), scenes.translation(0.0, 0.3, 0.0))
+    b.add_object(floor, b.add_material(albedo=(0.5, 0.5, 0.5)), scenes.translation(0.0, -1.6, 0.0) @ np.diag([8.0, 1.0, 8.0, 1.0]))
+    b.add_object(floor, b.add_material(albedo=(0, 0, 0), emissive=(6, 6, 6)), scenes.translation(2.5, 3.0, 1.0))
+    scene = b.build("bumpy_sphere", scenes.Camera((0, 1.5, 5), (0, 0, 0)), sky_color=(0.3, 0.4, 0.6), width=160, height=120, samples=3, bounces=6)
+    assert scene.n_triangles == 20024
+    frame = scene.frame()
+    got = render_all(scene, frame, abi.PT_ACCEL_AUTO)
+    assert got["accel"]["errors"] == 0 and got["stats"]["accel_used"] & 2
+    brute = render_all(scene, frame, abi.PT_ACCEL_BRUTE)
+    assert np.array_equal(got["image"].view(np.uint32), brute["image"].view(np.uint32))
+    assert np.array_equal(got["primary_flat_id"], brute["primary_flat_id"])
+    assert np.array_equal(got["primary_t"].view(np.uint32), brute["primary_t"].view(np.uint32))
+    assert np.array_equal(got["ray_count"], brute["ray_count"])
+    assert (got["primary_object"] == 0).mean() > 0.1
+    rect = (70, 50, 90, 62)
+    x0, y0, x1, y1 = rect
+    ref = oracle_render(scene, frame, rect=rect)
+    assert np.array_equal(got["image"][y0:y1, x0:x1].view(np.uint32), ref["image"].view(np.uint32))
+    assert np.array_equal(got["primary_flat_id"][y0:y1, x0:x1], ref["primary_flat_id"])
+
+
 def test_many_refits_then_a_fresh_build():
     """Refits keep a topology that fits the moved objects worse and worse, so every 16th update builds afresh; the trees
     must be valid after every update and the image that of a fresh context."""
