@@ -17,9 +17,10 @@ streams, so the start of a frame overlaps the tail of the previous one; results 
 Every step is a new frame the way the reference makes one (src/raytrace.wgsl:210, src/extract.rs:297-346): `time`
 advances, so every pixel draws new random numbers, and the object array is handed over again (unchanged, as the example
 scenes are static). The timed region of K steps is repeated (--repeats, fewer for workloads of seconds per repeat);
-`value` and `ms_per_step` are the median repeat, the fastest one is reported beside it. Two more timings of the same K
+`value` and `ms_per_step` are the median repeat, the fastest one is reported beside it. Three more timings of the same K
 steps are reported: one frame at a time on one context (what a caller of the synchronous pt_render sees, without the
-copy to the host), and with the schedule hints from the previous frame switched off (what a moving camera gets).
+copy to the host), with a camera that swings about the view target by up to 0.002 rad per frame (the schedule hints then
+come from a slightly different view), and with the hints switched off (what the first frame after a cut gets).
 
 Prints ONE JSON line on rank 0.
 """
@@ -183,6 +184,30 @@ def main():
             return 0.0 if tiles else virtual_frame_time(rank)
         return virtual_frame_time(i if tiles else i * world + rank)
 
+    # a camera that flies (reference examples/common.rs:25-95): it swings about the view target, +-0.05 rad around the
+    # scene's own view (so that the work per frame stays what the other timings measure), at most 0.002 rad per frame
+    orbit = [False]
+    eye0 = np.asarray(scene.camera.eye, dtype=np.float64)
+    tgt0 = np.asarray(scene.camera.target, dtype=np.float64)
+    wfv0 = [float(frames[0].world_from_view[j]) for j in range(16)]
+
+    orbit_views = []   # made outside the timed regions: one period of 160 frames, then the resting view
+
+    def make_orbit_views():
+        d = eye0 - tgt0
+        for k in range(160):
+            a = 0.05 * np.sin(2.0 * np.pi * k / 160.0)   # at most 0.002 rad from one frame to the next
+            eye = tgt0 + np.array([np.cos(a) * d[0] + np.sin(a) * d[2], d[1], -np.sin(a) * d[0] + np.cos(a) * d[2]])
+            wfv, _ = scenes.Camera(tuple(eye), tuple(tgt0), scene.camera.fov_y).matrices(W, H)
+            orbit_views.append((abi.C.c_float * 16)(*[float(x) for x in wfv]))
+        orbit_views.append((abi.C.c_float * 16)(*wfv0))
+
+    def set_view(fr, i):
+        if orbit[0]:
+            fr.world_from_view = orbit_views[i % 160]
+        elif orbit_views:
+            fr.world_from_view = orbit_views[160]
+
     def step(cs=None, one_at_a_time=False):
         cs = cs or ctxs
         n = len(cs)
@@ -192,6 +217,7 @@ def main():
         buf = bufs[k]
         fr = frames[k]
         fr.time = frame_time(i)
+        set_view(fr, i)
         cs[k].upload_objects(scene.objects)      # extract_visible hands the objects over every frame; unchanged here
         if world == 1:
             cs[k].render_device(fr, buf.data_ptr(), streams[k].cuda_stream)
@@ -276,7 +302,12 @@ def main():
     n_rep_other = max(1, min(len(times), 5))
     # the same K steps, one frame at a time on one context: each frame complete before the next is enqueued
     times_one = timed([ctxs[0]], one_at_a_time=True, repeats=n_rep_other)
-    # ... and with the schedule hints off (the view changes every frame: the previous frame's ray counts say nothing)
+    # ... with a camera that moves a little every frame (the schedule hints then come from a slightly different view)
+    make_orbit_views()
+    orbit[0] = True
+    times_mv = timed(repeats=n_rep_other)
+    orbit[0] = False
+    # ... and with the schedule hints off (what a cut to another view gets: the previous frame's ray counts say nothing)
     os.environ["PT_AMD_NO_COST_HINTS"] = "1"
     ctxs_nh = [abi.Context(device=local_rank) for _ in range(F)]
     del os.environ["PT_AMD_NO_COST_HINTS"]
@@ -362,6 +393,7 @@ def main():
             "ms_per_step_all_repeats": [round(t / args.steps * 1e3, 4) for t in times],
             "ms_per_step_one_in_flight": round(float(np.median(times_one)) / args.steps * 1e3, 4),
             "ms_per_step_no_hints": round(float(np.median(times_nh)) / args.steps * 1e3, 4),
+            "ms_per_step_moving_camera": round(float(np.median(times_mv)) / args.steps * 1e3, 4),
             "step_definition": "a new frame per step: time advances (new seeds for every pixel, src/raytrace.wgsl:210) and the unchanged object array is "
                                "handed over again (src/extract.rs:297-346)" if not args.fixed_time else "the identical frame every step",
             "higher_is_better": True,

@@ -145,6 +145,7 @@ struct pt_ctx {
     uint32_t tlas_refits = 0;     // refits since that build
     bool tlas_refitted = false;   // the last object upload refitted
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
+    bool strict_hints = false;    // see render_enqueue
     bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
     FrameKey hint_key;
     uint64_t scene_version = 0;   // bumped by every upload
@@ -280,6 +281,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
         if (std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = true;
         if (const char* e = std::getenv("PT_AMD_CARRY_ACQUIRE")) ctx->carry_acquire = std::atoi(e) != 0;
+        if (const char* e = std::getenv("PT_AMD_STRICT_HINTS")) ctx->strict_hints = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_WALK_QUOTA")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->walk_quota = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_BLAS_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= (int)PT_WIDE_MAX_LEAF) ctx->blas_max_leaf = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_LDS_STACK")) { int v = std::atoi(e); if (v >= 4 && v <= (int)kMaxStackDepth) ctx->lds_stack_max = (uint32_t)v; }
@@ -944,16 +946,22 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         PT_HIP(ctx, hipMemsetAsync(w.aux_rays, 0, 4 * n_pix, s));
     }
     // Per-pixel ray counts of the previous frame, still in the aux plane, predict what this frame's pixels cost when
-    // it is the same view of the same scene (the usual case: a renderer that draws frame after frame). They only
-    // decide the order in which k_paths takes the pixels, never a result.
+    // it is a frame of the same size and sample count (the usual case: a renderer that draws frame after frame; a camera
+    // or an object that has moved a little since leaves most pixels looking at what they looked at). They only decide
+    // the order in which k_paths takes the pixels, never a result. strict_hints: only for the same view of the same
+    // scene, compared bytewise.
     FrameKey key;
     std::memset(&key, 0, sizeof key);
     key.scene_version = ctx->scene_version;
     key.width = f->width; key.height = f->height;
     key.samples = f->settings.samples; key.bounces = f->settings.bounces;
     key.part_index = f->part_index; key.part_count = pc;
-    std::memcpy(key.wfv, f->world_from_view, sizeof key.wfv);
-    std::memcpy(key.vfc, f->view_from_clip, sizeof key.vfc);
+    if (ctx->strict_hints) {
+        std::memcpy(key.wfv, f->world_from_view, sizeof key.wfv);
+        std::memcpy(key.vfc, f->view_from_clip, sizeof key.vfc);
+    } else {
+        key.scene_version = 0;
+    }
     const bool use_hint = !noalloc && ctx->hint_valid && std::memcmp(&key, &ctx->hint_key, sizeof key) == 0 && ctx->cost_hints &&
                           f->settings.samples >= 8u && f->settings.bounces > 1u;
     ctx->hint_valid = false;   // until this frame has been enqueued completely

@@ -468,6 +468,26 @@ def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
             run(2)
 
 
+def test_hints_from_another_view_change_no_result():
+    """The schedule hints are taken from the context's previous frame even when the camera has moved since: the frame
+    must be what a fresh context renders."""
+    scene = scenes.boxes(320, 180, 16, 10)
+    frame_a = scene.frame(time=0.5)
+    cam_b = scenes.Camera(tuple(np.asarray(scene.camera.eye) + np.array([0.4, 0.1, -0.3])), scene.camera.target, scene.camera.fov_y)
+    wfv, vfc = cam_b.matrices(320, 180)
+    frame_b = abi.make_frame(wfv, vfc, 320, 180, time=1.5, bounces=10, samples=16, sky_color=scene.sky_color)
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        want = ctx.render(frame_b)
+        want_rays = ctx.read_aux(abi.PT_AUX_RAY_COUNT)
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        ctx.render(frame_a)
+        got = ctx.render(frame_b)       # ordered by the ray counts of frame_a
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), want_rays)
+
+
 def test_partition_union_equals_full_frame():
     scene = scenes.boxes(200, 120, 4, 10)
     full = render_all(scene, scene.frame())
