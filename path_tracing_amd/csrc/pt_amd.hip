@@ -25,6 +25,7 @@ namespace {
 constexpr uint32_t kBlasMinTris = 16;   // PT_ACCEL_AUTO: meshes with more triangles than this get a BLAS
 constexpr uint32_t kTlasMinObjects = 12; // PT_ACCEL_AUTO: scenes with more objects than this get a TLAS
 constexpr uint32_t kMaxStackDepth = 96;
+constexpr uint32_t kSahHostMaxTris = 1u << 17;     // meshes up to this many triangles get their BLAS from the host-side builder
 constexpr uint32_t kCollapseOneGroupMax = 4096;   // primitives up to which one workgroup makes the whole wide tree
 constexpr uint32_t kTlasMaxRefits = 15;  // object uploads that may refit the TLAS before it is built afresh  // LDS: 4 waves * depth * 256 B per workgroup
 
@@ -145,6 +146,7 @@ struct pt_ctx {
     uint32_t tlas_refits = 0;     // refits since that build
     bool tlas_refitted = false;   // the last object upload refitted
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
+    bool blas_sah = true;         // BLAS of moderate meshes by the surface-area heuristic on the host (else Morton order)
     bool strict_hints = false;    // see render_enqueue
     bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
     FrameKey hint_key;
@@ -219,6 +221,140 @@ int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t
     return PT_OK;
 }
 
+// ---- binary BVH over n boxes by the surface-area heuristic, made on the host ---------------------------------------------
+// For the BLAS of meshes of moderate size: a mesh is uploaded once and walked by every ray of every frame, so the better
+// tree is worth the milliseconds (16 bins per axis; where no plane separates the centroids the range is cut in the
+// middle). Produces exactly what build_lbvh() leaves behind for a BLAS: the nodes (root = node 0, leaves referenced by
+// sorted position), the sorted order in t_vals0, the range of positions below every node in t_ranges, the depth in
+// info_slot[0]. The boxes are unions of the very boxes the device computed for the triangles.
+int build_sah_host(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t first, uint32_t n, BvhNode* nodes,
+                   uint32_t node_base, uint32_t* info_slot) {
+    hipStream_t s = ctx->stream;
+    std::vector<float4> lo(n), hi(n);
+    PT_HIP(ctx, hipMemcpyAsync(lo.data(), box_lo + first, sizeof(float4) * n, hipMemcpyDeviceToHost, s));
+    PT_HIP(ctx, hipMemcpyAsync(hi.data(), box_hi + first, sizeof(float4) * n, hipMemcpyDeviceToHost, s));
+    PT_HIP(ctx, hipStreamSynchronize(s));
+    struct Box { float lo[3], hi[3]; };
+    auto empty = [] { Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = 3.0e38f; b.hi[a] = -3.0e38f; } return b; };
+    auto grow = [&](Box& b, uint32_t p) {
+        const float l[3] = {lo[p].x, lo[p].y, lo[p].z}, h[3] = {hi[p].x, hi[p].y, hi[p].z};
+        for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], l[a]); b.hi[a] = std::max(b.hi[a], h[a]); }
+    };
+    auto merge = [](Box& b, const Box& o) { for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], o.lo[a]); b.hi[a] = std::max(b.hi[a], o.hi[a]); } };
+    auto area = [](const Box& b) {
+        const double dx = std::max(0.0f, b.hi[0] - b.lo[0]), dy = std::max(0.0f, b.hi[1] - b.lo[1]), dz = std::max(0.0f, b.hi[2] - b.lo[2]);
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::vector<float> cen(3 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {
+        cen[3 * (size_t)i] = 0.5f * lo[i].x + 0.5f * hi[i].x;
+        cen[3 * (size_t)i + 1] = 0.5f * lo[i].y + 0.5f * hi[i].y;
+        cen[3 * (size_t)i + 2] = 0.5f * lo[i].z + 0.5f * hi[i].z;
+    }
+    std::vector<BvhNode> out(n - 1);
+    std::vector<uint2> ranges(n - 1);
+    struct Task { uint32_t node, lo, hi; };
+    std::vector<Task> stack;
+    stack.push_back({0u, 0u, n - 1u});
+    uint32_t next_node = 1;
+    constexpr int kBins = 16;
+    while (!stack.empty()) {
+        const Task t = stack.back();
+        stack.pop_back();
+        ranges[t.node] = make_uint2(t.lo, t.hi);
+        float cmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (uint32_t k = t.lo; k <= t.hi; ++k)
+            for (int a = 0; a < 3; ++a) { const float c = cen[3 * (size_t)order[k] + a]; cmin[a] = std::min(cmin[a], c); cmax[a] = std::max(cmax[a], c); }
+        int best_axis = -1, best_plane = 0;
+        double best_cost = 1.0e300;
+        float best_scale = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            const float ext = cmax[a] - cmin[a];
+            if (!(ext > 0.0f)) continue;
+            const float scale = (float)kBins / ext;
+            Box bb[kBins];
+            uint32_t cnt[kBins] = {};
+            for (int b = 0; b < kBins; ++b) bb[b] = empty();
+            for (uint32_t k = t.lo; k <= t.hi; ++k) {
+                const uint32_t p = order[k];
+                const int b = std::min(kBins - 1, std::max(0, (int)((cen[3 * (size_t)p + a] - cmin[a]) * scale)));
+                cnt[b]++;
+                grow(bb[b], p);
+            }
+            double right_area[kBins];
+            uint32_t right_cnt[kBins];
+            Box acc = empty();
+            uint32_t c = 0;
+            for (int b = kBins - 1; b >= 1; --b) { merge(acc, bb[b]); c += cnt[b]; right_area[b] = area(acc); right_cnt[b] = c; }
+            acc = empty();
+            c = 0;
+            for (int b = 0; b < kBins - 1; ++b) {   // plane between bin b and b + 1
+                merge(acc, bb[b]);
+                c += cnt[b];
+                if (c == 0 || right_cnt[b + 1] == 0) continue;
+                const double cost = area(acc) * c + right_area[b + 1] * right_cnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_plane = b; best_scale = scale; }
+            }
+        }
+        uint32_t mid;   // last position of the left part
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            uint32_t i = t.lo, j = t.hi;
+            auto left = [&](uint32_t p) { return std::min(kBins - 1, std::max(0, (int)((cen[3 * (size_t)p + a] - cmin[a]) * best_scale))) <= best_plane; };
+            while (true) {
+                while (i <= j && left(order[i])) ++i;
+                while (i < j && !left(order[j])) --j;
+                if (i >= j) break;
+                std::swap(order[i], order[j]);
+                ++i; --j;
+            }
+            mid = i - 1u;   // (both parts are non-empty: the plane was chosen with counts > 0 on both sides)
+        } else {
+            mid = t.lo + (t.hi - t.lo) / 2u;
+        }
+        BvhNode& N = out[t.node];
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t a = side ? mid + 1u : t.lo, b = side ? t.hi : mid;
+            Box bx = empty();
+            for (uint32_t k = a; k <= b; ++k) grow(bx, order[k]);
+            uint32_t ref;
+            if (a == b) {
+                ref = PT_LEAF_BIT | a;
+            } else {
+                const uint32_t child = next_node++;
+                ref = node_base + child;
+                stack.push_back({child, a, b});
+            }
+            uint32_t bits = ref;
+            float w;
+            std::memcpy(&w, &bits, sizeof w);
+            if (side == 0) { N.lo_l = make_float4(bx.lo[0], bx.lo[1], bx.lo[2], w); N.hi_l = make_float4(bx.hi[0], bx.hi[1], bx.hi[2], 0.0f); }
+            else { N.lo_r = make_float4(bx.lo[0], bx.lo[1], bx.lo[2], w); N.hi_r = make_float4(bx.hi[0], bx.hi[1], bx.hi[2], 0.0f); }
+        }
+    }
+    // subtree depths, as k_fit records them (a node's children have larger numbers than the node)
+    std::vector<uint32_t> depth(n - 1, 0);
+    auto ref_of = [](float w) { uint32_t b; std::memcpy(&b, &w, sizeof b); return b; };
+    auto as_float = [](uint32_t b) { float w; std::memcpy(&w, &b, sizeof w); return w; };
+    for (uint32_t i = n - 1; i-- > 0;) {
+        const uint32_t rl = ref_of(out[i].lo_l.w), rr = ref_of(out[i].lo_r.w);
+        const uint32_t dl = (rl & PT_LEAF_BIT) ? 0u : depth[rl - node_base], dr = (rr & PT_LEAF_BIT) ? 0u : depth[rr - node_base];
+        out[i].hi_l.w = as_float(dl);
+        out[i].hi_r.w = as_float(dr);
+        depth[i] = std::max(dl, dr) + 1u;
+    }
+    PT_HIP(ctx, ctx->t_vals0.ensure(sizeof(uint32_t) * n));
+    PT_HIP(ctx, ctx->t_ranges.ensure(sizeof(uint2) * n));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->t_vals0.p, order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->t_ranges.p, ranges.data(), sizeof(uint2) * (n - 1), hipMemcpyHostToDevice, s));
+    PT_HIP(ctx, hipMemcpyAsync(nodes, out.data(), sizeof(BvhNode) * (n - 1), hipMemcpyHostToDevice, s));
+    PT_HIP(ctx, hipMemcpyAsync(info_slot, &depth[0], sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    PT_HIP(ctx, hipStreamSynchronize(s));   // (the host vectors go out of scope)
+    return PT_OK;
+}
+
 // The 4-wide tree the rays walk, from a binary tree of n - 1 nodes over n primitives (k_collapse). info (device):
 // {nodes, levels, root reference, stack entries a walk can need}.
 // binary_depth (device): the word k_fit left the binary tree's depth in; a wide tree has at most that many levels.
@@ -281,6 +417,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
         if (std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = true;
         if (const char* e = std::getenv("PT_AMD_CARRY_ACQUIRE")) ctx->carry_acquire = std::atoi(e) != 0;
+        if (const char* e = std::getenv("PT_AMD_BLAS_BUILDER")) ctx->blas_sah = std::strcmp(e, "lbvh") != 0;
         if (const char* e = std::getenv("PT_AMD_STRICT_HINTS")) ctx->strict_hints = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_WALK_QUOTA")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->walk_quota = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_BLAS_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= (int)PT_WIDE_MAX_LEAF) ctx->blas_max_leaf = (uint32_t)v; }
@@ -465,7 +602,10 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
             const uint32_t first = hm[m].tri_first, cnt = hm[m].tri_count;
             uint32_t* info = ctx->t_info.as<uint32_t>() + 8 * (size_t)m;
             BvhNode* bn = ctx->d_blas_bnodes.as<BvhNode>() + node_base[m];
-            int rc = build_lbvh(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), first, cnt, bn, node_base[m], info, true);
+            // moderate meshes get the better tree from the host, very large ones the fast one from the device
+            int rc = (ctx->blas_sah && cnt <= kSahHostMaxTris)
+                         ? build_sah_host(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), first, cnt, bn, node_base[m], info)
+                         : build_lbvh(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), first, cnt, bn, node_base[m], info, true);
             if (rc != PT_OK) return rc;
             // the mesh's triangle records in the order of the tree's leaves, and which triangle each one is
             PT_HIP(ctx, ctx->t_tris_tmp.ensure(sizeof(DTri) * (size_t)cnt));
