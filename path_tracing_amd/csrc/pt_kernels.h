@@ -31,7 +31,7 @@
 
 // One entry of the path list: what k_primary found for a pixel that needs paths. 64 B, constant during k_paths.
 struct PathRec {
-    float4 a;  // bits(pix), bits(object of the primary hit), hit uv.x, hit uv.y
+    float4 a;  // bits(pix), bits(material of the primary hit), hit uv.x, hit uv.y
     float4 b;  // hit p.xyz, hit n.x
     float4 c;  // hit n.y, hit n.z, primary dir.x, primary dir.y
     float4 d;  // primary dir.z, bits(rng seed x), bits(seed y), bits(seed z)
@@ -167,8 +167,8 @@ PT_DEV uint32_t wave_sum_u32(uint32_t v) {
 // black (src/raytrace.wgsl:245-248). `c` is what the path adds: fma(ray_color = 1, emissive or sky, color = 0).
 PT_DEV bool primary_is_terminal(const SceneView& sc, const HitInfo& h, v3 sky, v3& c) {
     c = sky;
-    if (h.obj != PT_NONE) {
-        const DMaterial m = sc.materials[sc.objects[h.obj].mat];
+    if (h.mat != PT_NONE) {
+        const DMaterial m = sc.materials[h.mat];
         const v3 alb = V3(m.albedo[0], m.albedo[1], m.albedo[2]);
         if (!(dot3(alb, alb) < PT_EPSILON)) return false;
         c = V3(m.emissive[0], m.emissive[1], m.emissive[2]);
@@ -250,12 +250,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
     bool to_list = false;
     uint32_t hint = 0;  // rays beyond one per sample that this pixel took in the previous frame (0 when unknown)
     HitInfo h;
-    h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
+    h.mat = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
     if (valid) {
         if (STATS && b.obj != PT_NONE) cnt.hits++;
         h = finalize_hit(sc, origin, dir0, b);
         aux_obj[pix] = b.obj;
-        aux_flat[pix] = (b.obj != PT_NONE) ? sc.objects[b.obj].tri_base + b.tri : PT_NONE;
+        aux_flat[pix] = (b.obj != PT_NONE) ? sc.objects[b.obj].tri_base + (b.tri - sc.objects[b.obj].tri_first) : PT_NONE;
         aux_t[pix] = b.t;
         v3 c;
         if (primary_is_terminal(sc, h, V3(fp.sky[0], fp.sky[1], fp.sky[2]), c)) {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
         for (uint32_t w = 0; w < wave; ++w) base += s_count[w];
         if (to_list) {
             PathRec r;
-            r.a = make_float4(__uint_as_float(pix), __uint_as_float(h.obj), h.u, h.v);
+            r.a = make_float4(__uint_as_float(pix), __uint_as_float(h.mat), h.u, h.v);
             r.b = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
             r.c = make_float4(h.n.y, h.n.z, dir0.x, dir0.y);
             r.d = make_float4(dir0.z, __uint_as_float(seed_x), __uint_as_float(seed_y), __uint_as_float(seed_z));
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
     v3 rpos = origin, rdir = V3(0, 0, 1);
     v3 ray_color = V3(1, 1, 1), color = V3(0, 0, 0);
     HitInfo h;
-    h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
+    h.mat = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
     // PT_MODE_TLAS: a lane's TLAS walk survives the rounds of the loop below (see wide_walk_resume)
     WalkState ws = {PT_WALK_DONE, 0};
     Best wb;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                         const uint32_t entry = chunk_next + rank;
                         const PathRec* r = &recs[entry];
                         const float4 ra = r->a, rb = r->b, rc = r->c, rd = r->d;
-                        h.obj = __float_as_uint(ra.y);
+                        h.mat = __float_as_uint(ra.y);
                         h.u = ra.z; h.v = ra.w;
                         h.p = V3(rb.x, rb.y, rb.z);
                         h.n = V3(rb.w, rc.x, rc.y);
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                         slot_u[PT_SLOT_PIX * 64] = __float_as_uint(ra.x);
                         if (MODE == PT_MODE_LDS) {
                             // the sample-independent part of scattering off the primary hit, once per pixel and sweep
-                            const DMaterial pm = sc.materials[sc.objects[h.obj].mat];
+                            const DMaterial pm = sc.materials[h.mat];
                             v3 N = h.n;
                             if (pm.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, pm.normal_map_texture, h.u, h.v));
                             const BrdfFrame f = brdf_frame(sc, rdir, N, h.u, h.v, pm);
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
             rdir = V3(slot[(PT_SLOT_DIR + 0) * 64], slot[(PT_SLOT_DIR + 1) * 64], slot[(PT_SLOT_DIR + 2) * 64]);
             ray_color = V3(1, 1, 1);
             color = V3(0, 0, 0);
-            h.obj = slot_u[(PT_SLOT_HIT + 0) * 64];
+            h.mat = slot_u[(PT_SLOT_HIT + 0) * 64];
             h.p = V3(slot[(PT_SLOT_HIT + 1) * 64], slot[(PT_SLOT_HIT + 2) * 64], slot[(PT_SLOT_HIT + 3) * 64]);
             h.n = V3(slot[(PT_SLOT_HIT + 4) * 64], slot[(PT_SLOT_HIT + 5) * 64], slot[(PT_SLOT_HIT + 6) * 64]);
             h.u = slot[(PT_SLOT_HIT + 7) * 64];
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
         };
         // what the surface emits, and whether the path stops on it (black albedo)
         auto add_emitted = [&]() -> bool {
-            const DMaterial* m = &sc.materials[sc.objects[h.obj].mat];
+            const DMaterial* m = &sc.materials[h.mat];
             v3 emissive = V3(m->emissive[0], m->emissive[1], m->emissive[2]);
             const uint32_t et = m->emissive_texture;
             if (et != PT_NONE) emissive = sample_texture(sc, et, h.u, h.v);
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
         // making the whole wave loop here.
         bool pending = st == PT_ST_SHADE || st == PT_ST_RESTART;
         if (st == PT_ST_RESTART) {
-            h.obj = slot_u[(PT_SLOT_HIT + 0) * 64];
+            h.mat = slot_u[(PT_SLOT_HIT + 0) * 64];
             h.p = V3(slot[(PT_SLOT_HIT + 1) * 64], slot[(PT_SLOT_HIT + 2) * 64], slot[(PT_SLOT_HIT + 3) * 64]);
             h.n = V3(slot[(PT_SLOT_HIT + 4) * 64], slot[(PT_SLOT_HIT + 5) * 64], slot[(PT_SLOT_HIT + 6) * 64]);
             h.u = slot[(PT_SLOT_HIT + 7) * 64];
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
             if (pending) {
                 bool stop;
                 PT_COUNT(cnt, 1);
-                if (h.obj != PT_NONE) {
+                if (h.mat != PT_NONE) {
                     PT_COUNT(cnt, 2);
                     stop = add_emitted();
                     // Scatters whose only surviving effect is the one random draw of cosine_sample: the hit of a
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
             // 3. (expensive) so every lane that still has work scatters in the same pass
             if (pending) {
                 PT_COUNT(cnt, 5);
-                const DMaterial m = sc.materials[sc.objects[h.obj].mat];
+                const DMaterial m = sc.materials[h.mat];
                 v3 N = h.n;
                 if (m.normal_map_texture != PT_NONE) N = mul3(N, sample_texture(sc, m.normal_map_texture, h.u, h.v));
                 v3 ndir, bcol;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
         }
         // No lane holds a hit that still has to be shaded at this point: say so, or the nine registers of the old
         // record stay occupied all through the closest-hit code.
-        h.obj = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
+        h.mat = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
         if (MODE == PT_MODE_TLAS) {
             // Lanes walk the TLAS until pp.walk_quota of them are through; those get their hit record and go back to
             // shading in the next round while the others' walks continue where they stopped. With incoherent rays
@@ -941,8 +941,8 @@ __global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, LdsScene ls, uin
     o.object = b.obj;
     o.t = b.t;
     if (b.obj != PT_NONE) {
-        o.triangle = b.tri;
-        o.flat_id = sc.objects[b.obj].tri_base + b.tri;
+        o.triangle = b.tri - sc.objects[b.obj].tri_first;
+        o.flat_id = sc.objects[b.obj].tri_base + o.triangle;
     } else {
         o.triangle = PT_NONE;
         o.flat_id = PT_NONE;

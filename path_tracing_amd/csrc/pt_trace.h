@@ -22,7 +22,7 @@ struct Best {
 };
 
 struct HitInfo {
-    uint32_t obj;
+    uint32_t mat;   // material of the object that was hit (what shading needs of it), PT_NONE: nothing was hit
     v3 p, n;
     float u, v;  // hit_record.uv
 };
@@ -357,10 +357,10 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                 if (!slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), best.t, tn))
                     return;
             }
-            for (uint32_t i = 0; i < n; ++i) {
+            for (uint32_t g = tri_first; g < tri_first + n; ++g) {
                 PT_COUNT(cnt, 10);
-                const DTri* T = &sc.tris[tri_first + i];
-                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, best, cnt);
+                const DTri* T = &sc.tris[g];
+                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, g, sc.tie_lowest, best, cnt);
             }
         } else {
             const WideRay wr = make_wide_ray(make_slab_ray(lo, ld, pad));
@@ -370,9 +370,15 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
             wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r) { return reinterpret_cast<const uint4*>(nodes + r); }, root, wr, best.t, stk, sp0, true, cnt,
                                             [&](uint32_t leaf, int) {
                 const uint32_t pos = leaf & PT_WLEAF_POS_MASK, n = (leaf >> PT_WLEAF_COUNT_SHIFT) + 1u;
-                for (uint32_t j = 0; j < n; ++j) {
+                // (the first two triangles of a leaf are fetched together: one trip to memory instead of two)
+                const uint32_t p1 = pos + (n > 1u ? 1u : 0u);
+                const DTri A = tris[pos], B = tris[p1];
+                const uint32_t ia = ids[pos], ib = ids[p1];
+                changed |= tri_test<STATS>(A.q0, A.q1, A.q2, lo, ld, obj, tri_first + ia, sc.tie_lowest, best, cnt);
+                if (n > 1u) changed |= tri_test<STATS>(B.q0, B.q1, B.q2, lo, ld, obj, tri_first + ib, sc.tie_lowest, best, cnt);
+                for (uint32_t j = 2; j < n; ++j) {
                     const DTri* T = &tris[pos + j];
-                    changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, ids[pos + j], sc.tie_lowest, best, cnt);
+                    changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri_first + ids[pos + j], sc.tie_lowest, best, cnt);
                 }
             });
         }
@@ -404,10 +410,10 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                     const bool inside = n <= PT_LOCAL_BOX_MIN_TRIS ||
                         slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn);
                     if (__any(inside)) {
-                        for (uint32_t i = 0; i < n; ++i) {
+                        for (uint32_t g = tri_first; g < tri_first + n; ++g) {
                             PT_COUNT(cnt, 10); PT_COUNT_LANES(cnt, 15, inside);
-                            const DTri* T = &sc.tris[tri_first + i];
-                            if (inside) changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, cand, cnt);
+                            const DTri* T = &sc.tris[g];
+                            if (inside) changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, g, sc.tie_lowest, cand, cnt);
                         }
                     }
                 } else {
@@ -416,9 +422,15 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                         wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r) { return reinterpret_cast<const uint4*>(nodes + r); }, root, wr, cand.t, stk, sp0, true, cnt,
                                                         [&](uint32_t leaf, int) {
                             const uint32_t pos = leaf & PT_WLEAF_POS_MASK, n = (leaf >> PT_WLEAF_COUNT_SHIFT) + 1u;
-                            for (uint32_t j = 0; j < n; ++j) {
+                            // (the first two triangles of a leaf are fetched together: one trip to memory instead of two)
+                            const uint32_t p1 = pos + (n > 1u ? 1u : 0u);
+                            const DTri A = tris[pos], B = tris[p1];
+                            const uint32_t ia = ids[pos], ib = ids[p1];
+                            changed |= tri_test<STATS>(A.q0, A.q1, A.q2, lo, ld, obj, tri_first + ia, sc.tie_lowest, cand, cnt);
+                            if (n > 1u) changed |= tri_test<STATS>(B.q0, B.q1, B.q2, lo, ld, obj, tri_first + ib, sc.tie_lowest, cand, cnt);
+                            for (uint32_t j = 2; j < n; ++j) {
                                 const DTri* T = &tris[pos + j];
-                                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, ids[pos + j], sc.tie_lowest, cand, cnt);
+                                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri_first + ids[pos + j], sc.tie_lowest, cand, cnt);
                             }
                         });
                     };
@@ -536,7 +548,7 @@ PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& be
 // The hit_record of the winner (reference src/query.wgsl:113-120), evaluated once per ray.
 PT_DEV HitInfo finalize_hit(const SceneView& sc, v3 ro, v3 rd, const Best& b) {
     HitInfo h;
-    h.obj = b.obj;
+    h.mat = PT_NONE;
     h.p = V3(0, 0, 0);
     h.n = V3(0, 0, 0);
     h.u = 0.0f;
@@ -546,7 +558,8 @@ PT_DEV HitInfo finalize_hit(const SceneView& sc, v3 ro, v3 rd, const Best& b) {
     const Affine w2l = ob->w2l, l2w = sc.obj_l2w[b.obj];
     v3 lo = xform_point(w2l, ro);
     v3 ld = xform_dir(w2l, rd);
-    const DTriAttr* A = &sc.tri_attrs[ob->tri_first + b.tri];
+    const DTriAttr* A = &sc.tri_attrs[b.tri];   // (Best::tri counts from the start of the triangle arrays: no wait for *ob)
+    h.mat = ob->mat;
     float4 a0 = A->q0, a1 = A->q1, a2 = A->q2, a3 = A->q3;
     float u = b.u, v = b.v;
     float w = 1.0f - u - v;
@@ -653,7 +666,7 @@ PT_DEV void calculate_brdf(const SceneView& sc, Rng& rng, v3 ray_dir, v3 N, floa
 // exactly zero, the other factor being finite and far from overflow, comes out as +-0; three such channels give
 // p = +-0 < EPSILON. Materials with an albedo texture or a normal map take the general path.
 PT_DEV bool scatter_goes_dark(const SceneView& sc, const HitInfo& h, v3 ray_dir, v3 ray_color) {
-    const DMaterial* m = &sc.materials[sc.objects[h.obj].mat];
+    const DMaterial* m = &sc.materials[h.mat];
     if (m->albedo_texture != PT_NONE || m->normal_map_texture != PT_NONE) return false;
     const float big = 1.0e30f;
     const float ax = m->albedo[0], ay = m->albedo[1], az = m->albedo[2];
