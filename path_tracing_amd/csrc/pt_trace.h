@@ -410,10 +410,17 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                     const bool inside = n <= PT_LOCAL_BOX_MIN_TRIS ||
                         slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn);
                     if (__any(inside)) {
-                        for (uint32_t g = tri_first; g < tri_first + n; ++g) {
+                        // two triangles per step: their records (scalar loads, the mesh being the same for all lanes here)
+                        // are on their way together (four per step cost more scalar registers than the waiting they save)
+                        const uint32_t g_end = tri_first + n;
+                        for (uint32_t g = tri_first; g < g_end; g += 2u) {
                             PT_COUNT(cnt, 10); PT_COUNT_LANES(cnt, 15, inside);
-                            const DTri* T = &sc.tris[g];
-                            if (inside) changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, g, sc.tie_lowest, cand, cnt);
+                            const bool two = g + 1u < g_end;
+                            const DTri A = sc.tris[g], B = sc.tris[two ? g + 1u : g];
+                            if (inside) {
+                                changed |= tri_test<STATS>(A.q0, A.q1, A.q2, lo, ld, obj, g, sc.tie_lowest, cand, cnt);
+                                if (two) changed |= tri_test<STATS>(B.q0, B.q1, B.q2, lo, ld, obj, g + 1u, sc.tie_lowest, cand, cnt);
+                            }
                         }
                     }
                 } else {
