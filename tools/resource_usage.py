@@ -18,6 +18,8 @@ KEYS = [("sgpr", "TotalSGPRs"), ("vgpr", "VGPRs"), ("agpr", "AGPRs"), ("scratch_
 
 
 def main():
+    if len(sys.argv) > 1 and not sys.argv[1].endswith(".txt"):
+        raise SystemExit("the argument is the file the table is written to (something.txt)")
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                         "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/pt_resource_usage.so",
                         str(ROOT / "path_tracing_amd" / "csrc" / "pt_amd.hip")], capture_output=True, text=True)
