@@ -253,9 +253,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
     h.mat = PT_NONE; h.p = V3(0, 0, 0); h.n = V3(0, 0, 0); h.u = 0.0f; h.v = 0.0f;
     if (valid) {
         if (STATS && b.obj != PT_NONE) cnt.hits++;
-        h = finalize_hit(sc, origin, dir0, b);
+        h = finalize_hit<MODE != PT_MODE_LDS>(sc, origin, dir0, b);
         aux_obj[pix] = b.obj;
-        aux_flat[pix] = (b.obj != PT_NONE) ? sc.objects[b.obj].tri_base + (b.tri - sc.objects[b.obj].tri_first) : PT_NONE;
+        aux_flat[pix] = (b.obj != PT_NONE) ? sc.objects[b.obj].tri_base + (b.tri - (MODE != PT_MODE_LDS ? sc.objects[b.obj].tri_first : 0u)) : PT_NONE;
         aux_t[pix] = b.t;
         v3 c;
         if (primary_is_terminal(sc, h, V3(fp.sky[0], fp.sky[1], fp.sky[2]), c)) {
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                     nrays++;
                     lane_rays++;
                     if (STATS && wb.obj != PT_NONE) cnt.hits++;
-                    h = finalize_hit(sc, rpos, rdir, wb);
+                    h = finalize_hit<MODE != PT_MODE_LDS>(sc, rpos, rdir, wb);
                     st = PT_ST_SHADE;
                 }
             }
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                 nrays++;
                 lane_rays++;
                 if (STATS && b.obj != PT_NONE) cnt.hits++;
-                h = finalize_hit(sc, rpos, rdir, b);
+                h = finalize_hit<MODE != PT_MODE_LDS>(sc, rpos, rdir, b);
                 st = PT_ST_SHADE;
             }
             PT_COUNT_CYCLES(cnt, 15, tf);   // list scenes: cycles of the hit records
@@ -936,12 +936,12 @@ __global__ __launch_bounds__(256) void k_query(PT_SCENE_PARAMS, LdsScene ls, uin
     Best b;
     closest_hit<MODE, false>(sc, ro, rd, valid, b, stk, cnt);
     if (!valid) return;
-    HitInfo h = finalize_hit(sc, ro, rd, b);
+    HitInfo h = finalize_hit<MODE != PT_MODE_LDS>(sc, ro, rd, b);
     DHit o;
     o.object = b.obj;
     o.t = b.t;
     if (b.obj != PT_NONE) {
-        o.triangle = b.tri - sc.objects[b.obj].tri_first;
+        o.triangle = b.tri - (MODE != PT_MODE_LDS ? sc.objects[b.obj].tri_first : 0u);
         o.flat_id = sc.objects[b.obj].tri_base + o.triangle;
     } else {
         o.triangle = PT_NONE;

@@ -17,7 +17,9 @@
 struct Best {
     float t;
     uint32_t obj;
-    uint32_t tri;
+    uint32_t tri;   // the triangle: counted from the start of the triangle arrays (so that its attributes can be fetched
+                    // without a look at the object record), except for scenes staged in LDS, where such a look costs
+                    // nothing and the triangle is counted within its mesh (one register less through the triangle loops)
     float u, v;
 };
 
@@ -357,10 +359,10 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                 if (!slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), best.t, tn))
                     return;
             }
-            for (uint32_t g = tri_first; g < tri_first + n; ++g) {
+            for (uint32_t i = 0; i < n; ++i) {   // (scenes staged in LDS number a hit's triangle within its mesh: see Best)
                 PT_COUNT(cnt, 10);
-                const DTri* T = &sc.tris[g];
-                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, g, sc.tie_lowest, best, cnt);
+                const DTri* T = &sc.tris[tri_first + i];
+                changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, i, sc.tie_lowest, best, cnt);
             }
         } else {
             const WideRay wr = make_wide_ray(make_slab_ray(lo, ld, pad));
@@ -370,15 +372,10 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
             wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r) { return reinterpret_cast<const uint4*>(nodes + r); }, root, wr, best.t, stk, sp0, true, cnt,
                                             [&](uint32_t leaf, int) {
                 const uint32_t pos = leaf & PT_WLEAF_POS_MASK, n = (leaf >> PT_WLEAF_COUNT_SHIFT) + 1u;
-                // (the first two triangles of a leaf are fetched together: one trip to memory instead of two)
-                const uint32_t p1 = pos + (n > 1u ? 1u : 0u);
-                const DTri A = tris[pos], B = tris[p1];
-                const uint32_t ia = ids[pos], ib = ids[p1];
-                changed |= tri_test<STATS>(A.q0, A.q1, A.q2, lo, ld, obj, tri_first + ia, sc.tie_lowest, best, cnt);
-                if (n > 1u) changed |= tri_test<STATS>(B.q0, B.q1, B.q2, lo, ld, obj, tri_first + ib, sc.tie_lowest, best, cnt);
-                for (uint32_t j = 2; j < n; ++j) {
+                // (one triangle at a time here: the records are in LDS, and two in flight cost this variant registers)
+                for (uint32_t j = 0; j < n; ++j) {
                     const DTri* T = &tris[pos + j];
-                    changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri_first + ids[pos + j], sc.tie_lowest, best, cnt);
+                    changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, ids[pos + j], sc.tie_lowest, best, cnt);
                 }
             });
         }
@@ -553,6 +550,8 @@ PT_DEV void closest_hit(const SceneView& sc, v3 ro, v3 rd, bool active, Best& be
 }
 
 // The hit_record of the winner (reference src/query.wgsl:113-120), evaluated once per ray.
+// GLOBAL_TRI: how Best::tri counts (see there).
+template <bool GLOBAL_TRI>
 PT_DEV HitInfo finalize_hit(const SceneView& sc, v3 ro, v3 rd, const Best& b) {
     HitInfo h;
     h.mat = PT_NONE;
@@ -565,7 +564,7 @@ PT_DEV HitInfo finalize_hit(const SceneView& sc, v3 ro, v3 rd, const Best& b) {
     const Affine w2l = ob->w2l, l2w = sc.obj_l2w[b.obj];
     v3 lo = xform_point(w2l, ro);
     v3 ld = xform_dir(w2l, rd);
-    const DTriAttr* A = &sc.tri_attrs[b.tri];   // (Best::tri counts from the start of the triangle arrays: no wait for *ob)
+    const DTriAttr* A = &sc.tri_attrs[GLOBAL_TRI ? b.tri : ob->tri_first + b.tri];
     h.mat = ob->mat;
     float4 a0 = A->q0, a1 = A->q1, a2 = A->q2, a3 = A->q3;
     float u = b.u, v = b.v;
