@@ -138,7 +138,7 @@ struct pt_ctx {
     uint32_t walk_quota = 16;     // see PathParams::walk_quota
     uint32_t blas_max_leaf = 2;   // triangles a BLAS leaf holds at most (1..PT_WIDE_MAX_LEAF); 2 measured best on the 968-triangle mesh of scene.glb
     bool carry_acquire = true;    // see PathParams::carry_acquire (costs about 1 % of a frame; PT_AMD_CARRY_ACQUIRE=0 leaves it out)
-    bool split_chunks = false;    // see PathParams::split_chunks: shorter single frames on scenes of long BVH walks, fewer frames per second when several are in flight
+    bool split_chunks = true;     // see PathParams::split_chunks: the most expensive chunks of list-mode scenes in four parts (shorter single frames, and more frames per second since the workgroups of such scenes leave wave slots free)
     bool lds_blas = true;         // object-list scenes: stage the biggest BLAS that fits in LDS (k_paths)
     uint32_t lds_per_cu = 160 * 1024;
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
@@ -415,7 +415,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (const char* e = std::getenv("PT_AMD_REFILL_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_min = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
-        if (std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = true;
+        if (const char* e = std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_CARRY_ACQUIRE")) ctx->carry_acquire = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_BLAS_BUILDER")) ctx->blas_sah = std::strcmp(e, "lbvh") != 0;
         if (const char* e = std::getenv("PT_AMD_STRICT_HINTS")) ctx->strict_hints = std::atoi(e) != 0;

@@ -341,8 +341,8 @@ def test_scene_glb_1080p_accel_invariance_and_oracle_crop(monkeypatch):
             img = ctx.render(frame)
             assert np.array_equal(img.view(np.uint32), a["image"].view(np.uint32))
             assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), a["ray_count"])
-    with monkeypatch.context() as mp:   # the most expensive chunks handed out in parts of 16 entries
-        mp.setenv("PT_AMD_SPLIT_CHUNKS", "1")
+    with monkeypatch.context() as mp:   # the most expensive chunks handed out whole instead of in parts of 16 entries
+        mp.setenv("PT_AMD_SPLIT_CHUNKS", "0")
         with abi.Context() as ctx:
             ctx.upload_scene(scene)
             for _ in range(3):
@@ -461,7 +461,7 @@ def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
     run(3)   # (the glb scene: from the second frame on its big mesh's BLAS is staged in LDS)
     for env in ({"PT_AMD_SWEEPS": "1"}, {"PT_AMD_SWEEPS": "8"}, {"PT_AMD_NO_COST_HINTS": "1"}, {"PT_AMD_REFILL_MIN": "1"},
                 {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}, {"PT_AMD_NO_LDS_BLAS": "1"}, {"PT_AMD_WALK_QUOTA": "1"}, {"PT_AMD_WALK_QUOTA": "64"},
-                {"PT_AMD_SPLIT_CHUNKS": "1"}, {"PT_AMD_SPLIT_CHUNKS": "1", "PT_AMD_NO_LDS_SCENE": "1"}):
+                {"PT_AMD_SPLIT_CHUNKS": "0"}, {"PT_AMD_SPLIT_CHUNKS": "0", "PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_SPLIT_CHUNKS": "1", "PT_AMD_NO_LDS_SCENE": "1"}):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
