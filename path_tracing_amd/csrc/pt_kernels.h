@@ -327,8 +327,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
 #ifndef PT_SPLIT_PARTS
 #define PT_SPLIT_PARTS 4u
 #endif
+#ifndef PT_QUAD_TRACE
+#define PT_QUAD_TRACE 1   // 1: the rays of such a portion are traced by four lanes each (closest_hit_list_quad)
+#endif
 #ifndef PT_SPLIT_FRACTION
-#define PT_SPLIT_FRACTION 32u
+#define PT_SPLIT_FRACTION 16u
 #endif
 struct ChunkOrderInfo {
     uint32_t n_chunks, n_heavy, n_split, _pad;
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
     WalkState ws = {PT_WALK_DONE, 0};
     Best wb;
     wb.t = PT_T_MAX; wb.obj = PT_NONE; wb.tri = PT_NONE; wb.u = 0.0f; wb.v = 0.0f;
+    bool quad_wave = false;  // wave-uniform: the wave holds a portion of a split chunk, its pixels in lanes 0, 4, 8 ... (quads)
     bool exhausted = false;  // wave-uniform: the work queue has run out
     bool waiting = false;    // wave-uniform: holding an item whose chunk is not ready yet
     uint32_t first_entry = 0xFFFFFFFFu, n_chunks = 0;  // STATS only
@@ -586,7 +590,11 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                     const uint32_t avail = chunk_end - chunk_next;
                     const uint32_t want = (uint32_t)__popcll(m);
                     const uint32_t take = want < avail ? want : avail;
-                    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    // (a portion of a split chunk goes to every fourth lane: the lanes between help with its rays, see
+                    // closest_hit_list_quad)
+                    const bool quads = PT_QUAD_TRACE && solo && MODE != PT_MODE_LDS && MODE != PT_MODE_TLAS;
+                    const uint32_t rank = quads ? ((lane & 3u) ? 64u : (lane >> 2)) : (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (take != 0u) quad_wave = quads;
                     if (need && rank < take) {
                         need = false;
                         const uint32_t entry = chunk_next + rank;
@@ -827,6 +835,14 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
             const bool tracing = st == PT_ST_TRACE;
             Best b;
             cnt.passes = 0;
+            if (PT_QUAD_TRACE && MODE != PT_MODE_LDS && quad_wave) {
+                // 16 rays in this wave, in the first lane of every quad: the quads trace them together
+                const v3 qo = V3(quad_perm_f32<PT_QUAD_BCAST0>(rpos.x), quad_perm_f32<PT_QUAD_BCAST0>(rpos.y), quad_perm_f32<PT_QUAD_BCAST0>(rpos.z));
+                const v3 qd = V3(quad_perm_f32<PT_QUAD_BCAST0>(rdir.x), quad_perm_f32<PT_QUAD_BCAST0>(rdir.y), quad_perm_f32<PT_QUAD_BCAST0>(rdir.z));
+                const bool qa = quad_perm_u32<PT_QUAD_BCAST0>(tracing ? 1u : 0u) != 0u;
+                b.t = PT_T_MAX; b.obj = PT_NONE; b.tri = PT_NONE; b.u = 0.0f; b.v = 0.0f;
+                closest_hit_list_quad<STATS, MODE == PT_MODE_LIST_LB>(sc, qo, qd, qa, b, stk, cnt);
+            } else
             closest_hit<MODE, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
             if (STATS) n_passes += cnt.passes;
             // waves whose rays are expensive (many candidate objects) are the critical path of the launch: let them issue first

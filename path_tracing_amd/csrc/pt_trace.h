@@ -518,6 +518,198 @@ PT_DEV void closest_hit_list(const SceneView& sc, v3 ro, v3 rd, bool active, Bes
     }
 }
 
+// ---- hit_all for 16 rays per wave: four lanes to a ray ----------------------------------------------------------------
+// When a wave holds few rays (k_paths hands the most expensive pixels out in portions of 16), lanes 4j .. 4j+3 (a quad)
+// work on the ray of lane 4j together: each lane tests one child box of a BLAS node, one triangle of a leaf, every
+// fourth triangle of a mesh without a BLAS. A node visit is then ~70 instructions per lane instead of ~165, and the
+// pixels handed out this way are the frame's longest chains of dependent steps. The candidates, their arithmetic and the
+// winner rule are those of the one-lane-per-ray code, so the result is the same closest hit.
+// All 64 lanes are active in these functions; ray, closest hit and control flow are identical in the lanes of a quad,
+// only what is marked "own" differs. Cross-lane moves are DPP quad permutations (no LDS traffic).
+template <int CTRL>
+PT_DEV uint32_t quad_perm_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+PT_DEV float quad_perm_f32(float v) { return __uint_as_float(quad_perm_u32<CTRL>(__float_as_uint(v))); }
+#define PT_QUAD_BCAST0 0x00   // [0,0,0,0]
+#define PT_QUAD_XOR1 0xB1     // [1,0,3,2]
+#define PT_QUAD_XOR2 0x4E     // [2,3,0,1]
+#define PT_QUAD_ROT1 0x39     // [1,2,3,0]
+#define PT_QUAD_ROT2 0x4E     // [2,3,0,1]
+#define PT_QUAD_ROT3 0x93     // [3,0,1,2]
+PT_DEV float quad_min_f32(float v) {
+    v = pt_min(v, quad_perm_f32<PT_QUAD_XOR1>(v));
+    return pt_min(v, quad_perm_f32<PT_QUAD_XOR2>(v));
+}
+PT_DEV uint32_t quad_max_u32(uint32_t v) {
+    uint32_t w = quad_perm_u32<PT_QUAD_XOR1>(v);
+    v = v > w ? v : w;
+    w = quad_perm_u32<PT_QUAD_XOR2>(v);
+    return v > w ? v : w;
+}
+// The better of the quad's four closest-hit candidates (same object), in every lane.
+PT_DEV void quad_best(Best& b, uint32_t tie_lowest) {
+#define PT_QUAD_MERGE(CTRL) { \
+        const float pt_ = quad_perm_f32<CTRL>(b.t), pu_ = quad_perm_f32<CTRL>(b.u), pv_ = quad_perm_f32<CTRL>(b.v); \
+        const uint32_t po_ = quad_perm_u32<CTRL>(b.obj), pr_ = quad_perm_u32<CTRL>(b.tri); \
+        if (po_ != PT_NONE && candidate_wins(pt_, po_, pr_, b, tie_lowest)) { b.t = pt_; b.obj = po_; b.tri = pr_; b.u = pu_; b.v = pv_; } }
+    PT_QUAD_MERGE(PT_QUAD_XOR1)
+    PT_QUAD_MERGE(PT_QUAD_XOR2)
+#undef PT_QUAD_MERGE
+}
+// One visit of a wide node by a quad; `q` is the lane's number in its quad, its own child is child q. The stack column is
+// the quad leader's. Same contract as wide_visit().
+template <bool STATS, class Stk>
+PT_DEV uint32_t quad_visit(const uint4* N, uint32_t q, const WideRay& wr, float tmax, Stk stk, int& sp, int sp0, LaneCounters& cnt) {
+    const uint4 q0 = N[0], q2 = N[2], q3 = N[3];
+    const uint32_t ref = reinterpret_cast<const uint32_t*>(N)[4u + q];   // own child
+    const uint32_t exps = q0.w;
+    const float sx = __uint_as_float((exps << 23) & 0x7F800000u) * wr.inv.x;
+    const float sy = __uint_as_float((exps << 15) & 0x7F800000u) * wr.inv.y;
+    const float sz = __uint_as_float((exps << 7) & 0x7F800000u) * wr.inv.z;
+    const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
+    const uint32_t sh = 8u * q;
+    const uint32_t wnx = wr.nx ? q2.w : q2.x, wfx = wr.nx ? q2.x : q2.w;
+    const uint32_t wny = wr.ny ? q3.x : q2.y, wfy = wr.ny ? q2.y : q3.x;
+    const uint32_t wnz = wr.nz ? q3.y : q2.z, wfz = wr.nz ? q2.z : q3.y;
+    const float nx = pt_fma((float)((wnx >> sh) & 0xFFu), sx, pt_fma(ox, wr.inv.x, wr.kn.x)), fx = pt_fma((float)((wfx >> sh) & 0xFFu), sx, pt_fma(ox, wr.inv.x, wr.kf.x));
+    const float ny = pt_fma((float)((wny >> sh) & 0xFFu), sy, pt_fma(oy, wr.inv.y, wr.kn.y)), fy = pt_fma((float)((wfy >> sh) & 0xFFu), sy, pt_fma(oy, wr.inv.y, wr.kf.y));
+    const float nz = pt_fma((float)((wnz >> sh) & 0xFFu), sz, pt_fma(oz, wr.inv.z, wr.kn.z)), fz = pt_fma((float)((wfz >> sh) & 0xFFu), sz, pt_fma(oz, wr.inv.z, wr.kf.z));
+    const float tn = pt_max(pt_max(nx, ny), pt_max(nz, 0.0f));
+    const float tf = pt_min(pt_min(fx, fy), pt_min(fz, tmax));
+    const bool hit = (ref != PT_NONE) && (tn <= tf);
+    if (STATS && ref != PT_NONE) cnt.box_tests++;
+    // own key: entry distance with the quad lane in the two lowest bits (distinct keys, order = order of wide_visit's sort
+    // up to those two bits); 0xFFFFFFFF for a miss
+    const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | q) : 0xFFFFFFFFu;
+    const uint32_t k1 = quad_perm_u32<PT_QUAD_ROT1>(key), k2 = quad_perm_u32<PT_QUAD_ROT2>(key), k3 = quad_perm_u32<PT_QUAD_ROT3>(key);
+    const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);   // children the ray enters before the own one
+    const int n_hit = (int)hit + (int)(k1 != 0xFFFFFFFFu) + (int)(k2 != 0xFFFFFFFFu) + (int)(k3 != 0xFFFFFFFFu);
+    const int n_push = n_hit > 1 ? n_hit - 1 : 0;
+    if (hit && rank > 0) stk.put(sp + n_push - rank, ref);   // the farthest goes deepest
+    sp += n_push;
+    const uint32_t first = quad_max_u32((hit && rank == 0) ? ref + 1u : 0u);   // (+1: reference 0 is a node)
+    if (n_hit) return first - 1u;
+    return (sp > sp0) ? stk.get(--sp) : PT_WALK_DONE;
+}
+// hit_mesh for one object by the quads of a wave (see object_test); `best` stays identical in the lanes of a quad.
+template <bool STATS, bool LB, class Stk>
+PT_DEV void object_test_quad(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, uint32_t q, Best& best, Stk stk, LaneCounters& cnt) {
+    const DObject* ob = &sc.objects[obj];
+    const Affine w2l = ob->w2l;
+    const uint32_t mesh_id = ob->mesh;
+    const v3 lo = xform_point(w2l, ro);
+    const v3 ld = xform_dir(w2l, rd);
+    if (STATS && q == 0u) cnt.xforms++;
+    bool pending = true;
+    while (__any(pending)) {
+        if (pending) {
+            const uint32_t m = __builtin_amdgcn_readfirstlane(mesh_id);
+            uint32_t m_cmp = m;
+            asm volatile("" : "+s"(m_cmp));   // (see object_test)
+            if (mesh_id == m_cmp) {
+                pending = false;
+                const DMesh* me = &sc.meshes[m];
+                const uint32_t root = me->blas_root, tri_first = me->tri_first;
+                const float pad = 0x1p-18f * (pt_max(pt_max(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fabsf(lo.z)) + me->max_abs);
+                const SlabRay sr = make_slab_ray(lo, ld, pad);
+                Best cand = best;   // own: the closest hit with the triangles this lane tests
+                bool changed = false;
+                if (root == PT_NONE) {
+                    const uint32_t n = me->tri_count;
+                    float tn;
+                    if (STATS && q == 0u) cnt.box_tests++;
+                    const bool inside = n <= PT_LOCAL_BOX_MIN_TRIS ||
+                        slab_test(sr, make_float4(me->bmin[0], me->bmin[1], me->bmin[2], 0.0f), make_float4(me->bmax[0], me->bmax[1], me->bmax[2], 0.0f), cand.t, tn);
+                    if (inside) {
+                        for (uint32_t g = tri_first + q; g < tri_first + n; g += 4u) {   // own: every fourth triangle
+                            const DTri* T = &sc.tris[g];
+                            changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, g, sc.tie_lowest, cand, cnt);
+                        }
+                    }
+                } else {
+                    const WideRay wr = make_wide_ray(sr);
+                    Stk qstk = stk;
+                    qstk.base -= q;   // the quad leader's column
+                    auto walk = [&](const WNode* nodes, const DTri* tris, const uint32_t* ids) {
+                        uint32_t node = root;
+                        int sp = 0;
+                        float tmax = cand.t;   // the quad's closest hit so far (identical in its lanes)
+                        while (__any(node != PT_WALK_DONE)) {
+                            if (node != PT_WALK_DONE && !(node & PT_LEAF_BIT))
+                                node = quad_visit<STATS, Stk>(reinterpret_cast<const uint4*>(nodes + node), q, wr, tmax, qstk, sp, 0, cnt);
+                            if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
+                                const uint32_t leaf = node & ~PT_LEAF_BIT;
+                                const uint32_t pos = leaf & PT_WLEAF_POS_MASK, n = (leaf >> PT_WLEAF_COUNT_SHIFT) + 1u;
+                                if (q < n) {   // own: triangle q of the leaf (a leaf has at most four)
+                                    const DTri* T = &tris[pos + q];
+                                    changed |= tri_test<STATS>(T->q0, T->q1, T->q2, lo, ld, obj, tri_first + ids[pos + q], sc.tie_lowest, cand, cnt);
+                                }
+                                tmax = quad_min_f32(cand.t);
+                                node = (sp > 0) ? qstk.get(--sp) : PT_WALK_DONE;
+                            }
+                        }
+                    };
+                    if (LB && m == sc.lb_mesh) {
+                        if (sc.lb_tris) walk(sc.lb_nodes - sc.lb_node_base, sc.lb_tris, sc.lb_tri_ids);
+                        else walk(sc.lb_nodes - sc.lb_node_base, sc.tris + tri_first, sc.tri_ids + tri_first);
+                    } else {
+                        walk(sc.blas_nodes, sc.tris + tri_first, sc.tri_ids + tri_first);
+                    }
+                }
+                // the quad's winner, in all of its lanes; then the reference's gate, as in object_test
+                const unsigned long long cm = __ballot(changed);
+                const bool any_changed = ((cm >> ((threadIdx.x & 63u) & ~3u)) & 0xFull) != 0ull;
+                quad_best(cand, sc.tie_lowest);
+                if (any_changed) {
+                    const float t_aabb = hit_box_exact(me->bmin, me->bmax, lo, ld);
+                    if (!(t_aabb < PT_T_MIN)) best = cand;
+                }
+            }
+        }
+    }
+}
+// hit_all for the rays of the quads' leaders (see closest_hit_list; object lists only). ro, rd, active: the leader's,
+// replicated in its quad by the caller.
+template <bool STATS, bool LB, class Stk>
+PT_DEV void closest_hit_list_quad(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, Stk stk, LaneCounters& cnt) {
+    const uint32_t q = threadIdx.x & 3u;
+    const SlabRay sr = world_slab_ray(ro, rd);
+    const uint32_t n = sc.n_objects;
+    const bool cull = sc.cull_boxes != 0;
+    const uint32_t n_groups = (n + 31u) / 32u;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t base = g * 32u;
+        const uint32_t m = (n - base < 32u) ? n - base : 32u;
+        uint32_t mask = 0, near_k = 0;
+        float near_t = PT_T_MAX;
+        if (cull) {
+            for (uint32_t k = 0; k < m; ++k) {
+                float tn;
+                if (STATS && q == 0u) cnt.box_tests++;
+                if (slab_test(sr, sc.obj_lo[base + k], sc.obj_hi[base + k], best.t, tn)) {
+                    mask |= 1u << k;
+                    if (tn < near_t) { near_t = tn; near_k = k; }
+                }
+            }
+        } else {
+            mask = (m == 32u) ? 0xFFFFFFFFu : ((1u << m) - 1u);
+        }
+        if (!active) mask = 0;
+        bool first = cull;
+        while (__any(mask != 0)) {
+            cnt.passes++;
+            if (mask != 0) {
+                const uint32_t k = first ? near_k : (uint32_t)__builtin_ctz(mask);
+                const uint32_t o = base + k;
+                mask &= ~(1u << k);
+                float tn;
+                if (!cull || first || slab_test(sr, sc.obj_lo[o], sc.obj_hi[o], best.t, tn)) object_test_quad<STATS, LB>(sc, o, ro, rd, q, best, stk, cnt);
+            }
+            first = false;
+        }
+    }
+}
+
 // A TLAS node: from the copy of the tree's top levels in LDS when the kernel made one, else from global memory.
 PT_DEV const uint4* tlas_node_at(const SceneView& sc, uint32_t r) {
     const WNode* n = (r < sc.tlas_top_n) ? sc.tlas_top + r : sc.tlas_nodes + r;
