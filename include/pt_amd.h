@@ -377,7 +377,8 @@ int pt_device_info(pt_ctx* ctx, char* buf, size_t buf_bytes);
 
 /* Per-wave records of the last frame's k_paths launches when it was rendered with detailed statistics:
  * 16 x u32 per wave {start, end on the 100 MHz clock, lifetime in 16-cycle units, rounds, lane rounds, first list
- * position, items taken << 8 | XCC_ID, HW_ID, longest item: 16-cycle units, rounds, queue index, 5 x 0}.
+ * position, items taken << 8 | XCC_ID, HW_ID, longest item: 16-cycle units, rounds, queue index, 0, trace steps done with
+ * four lanes to a ray, 3 x 0}.
  * Copies at most out_bytes; *n_records = records available. Profiling aid, no counterpart in the reference. */
 int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n_records);
 

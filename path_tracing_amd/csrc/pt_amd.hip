@@ -146,6 +146,7 @@ struct pt_ctx {
     uint32_t tlas_refits = 0;     // refits since that build
     bool tlas_refitted = false;   // the last object upload refitted
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
+    uint32_t split_fraction = PT_SPLIT_FRACTION;   // at most 1/this of the chunks are handed out in parts
     bool blas_sah = true;         // BLAS of moderate meshes by the surface-area heuristic on the host (else Morton order)
     bool strict_hints = false;    // see render_enqueue
     bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
@@ -416,6 +417,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
         if (const char* e = std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = std::atoi(e) != 0;
+        if (const char* e = std::getenv("PT_AMD_SPLIT_FRACTION")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) ctx->split_fraction = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CARRY_ACQUIRE")) ctx->carry_acquire = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_BLAS_BUILDER")) ctx->blas_sah = std::strcmp(e, "lbvh") != 0;
         if (const char* e = std::getenv("PT_AMD_STRICT_HINTS")) ctx->strict_hints = std::atoi(e) != 0;
@@ -1251,7 +1253,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             uint32_t* order = ctx->d_chunk_order.as<uint32_t>();
             ChunkOrderInfo* info = reinterpret_cast<ChunkOrderInfo*>(order + max_chunks);
             k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(w.cost, dc, fp.samples, ctx->d_chunk_bin.as<uint32_t>());
-            k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info);
+            k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction);
             chunk_order = order;
             order_info = info;
         }

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__
     }
 }
 __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict__ chunk_bin, const DCounters* __restrict__ counters,
-                                                      uint32_t* __restrict__ order, ChunkOrderInfo* __restrict__ info) {
+                                                      uint32_t* __restrict__ order, ChunkOrderInfo* __restrict__ info, uint32_t split_fraction) {
     __shared__ uint32_t cnt[PT_COST_BINS], start[PT_COST_BINS];
     const uint32_t total = counters->n_paths;
     const uint32_t n_chunks = (total + PT_CHUNK - 1u) / PT_CHUNK;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
             run += cnt[b];
             if ((uint32_t)b >= PT_HEAVY_BIN) {
                 heavy = run;
-                if (top && run <= n_chunks / PT_SPLIT_FRACTION) split = run; else if (cnt[b]) top = false;
+                if (top && run <= n_chunks / split_fraction) split = run; else if (cnt[b]) top = false;
             }
         }
         info->n_chunks = n_chunks;
@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
     unsigned long long item_t0 = 0, item_r0 = 0, worst_cycles = 0, worst_rounds = 0;  // STATS only: the wave's longest item
     uint32_t worst_item = 0, cur_item = 0;
     unsigned long long cyc_refill = 0, cyc_trace = 0, cyc_shade = 0, n_rounds = 0, lane_rounds = 0, n_passes = 0;  // STATS only
+    uint32_t quad_rounds = 0;   // STATS only: trace steps this wave did with four lanes to a ray
 
     for (;;) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -841,6 +842,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                 const v3 qd = V3(quad_perm_f32<PT_QUAD_BCAST0>(rdir.x), quad_perm_f32<PT_QUAD_BCAST0>(rdir.y), quad_perm_f32<PT_QUAD_BCAST0>(rdir.z));
                 const bool qa = quad_perm_u32<PT_QUAD_BCAST0>(tracing ? 1u : 0u) != 0u;
                 b.t = PT_T_MAX; b.obj = PT_NONE; b.tri = PT_NONE; b.u = 0.0f; b.v = 0.0f;
+                if (STATS) quad_rounds++;
                 closest_hit_list_quad<STATS, MODE == PT_MODE_LIST_LB>(sc, qo, qd, qa, b, stk, cnt);
             } else
             closest_hit<MODE, STATS>(sc, rpos, rdir, tracing, b, stk, cnt);
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                 }
                 rec[1] = make_uint4((uint32_t)lane_rounds, first_entry, (n_chunks << 8) | (xcc_id & 15u), hw_id);
                 rec[2] = make_uint4((uint32_t)(worst_cycles >> 4), (uint32_t)worst_rounds, worst_item, 0u);
-                rec[3] = make_uint4(0u, 0u, 0u, 0u);
+                rec[3] = make_uint4(quad_rounds, 0u, 0u, 0u);
             }
             atomicAdd(&counters->cyc_refill, cyc_refill);
             atomicAdd(&counters->cyc_trace, cyc_trace);
