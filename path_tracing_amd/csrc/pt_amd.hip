@@ -147,6 +147,7 @@ struct pt_ctx {
     bool tlas_refitted = false;   // the last object upload refitted
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
     uint32_t split_fraction = PT_SPLIT_FRACTION;   // at most 1/this of the chunks are handed out in parts
+    uint32_t group_margin_8ths[2] = {12, 8};       // see ChunkOrderInfo::n_groups: waves = this/8 x work / longest chunk, {frame alone on the device, other frames running}; 0: always the whole grid
     bool blas_sah = true;         // BLAS of moderate meshes by the surface-area heuristic on the host (else Morton order)
     bool strict_hints = false;    // see render_enqueue
     bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
@@ -417,6 +418,12 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_NO_COST_HINTS")) ctx->cost_hints = false;
         if (std::getenv("PT_AMD_NO_REFIT")) ctx->allow_refit = false;
         if (const char* e = std::getenv("PT_AMD_SPLIT_CHUNKS")) ctx->split_chunks = std::atoi(e) != 0;
+        if (const char* e = std::getenv("PT_AMD_GROUP_MARGIN")) {   // "alone,shared" in eighths, or one number for both
+            int a = 0, b = 0;
+            const int n = std::sscanf(e, "%d,%d", &a, &b);
+            if (n == 1) b = a;
+            if (n >= 1 && a >= 0 && a <= 4096 && b >= 0 && b <= 4096) { ctx->group_margin_8ths[0] = (uint32_t)a; ctx->group_margin_8ths[1] = (uint32_t)b; }
+        }
         if (const char* e = std::getenv("PT_AMD_SPLIT_FRACTION")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) ctx->split_fraction = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CARRY_ACQUIRE")) ctx->carry_acquire = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_BLAS_BUILDER")) ctx->blas_sah = std::strcmp(e, "lbvh") != 0;
@@ -904,6 +911,7 @@ int finish_slot(pt_ctx* ctx, FrameSlot& sl) {
     PT_HIP(ctx, hipMemcpy(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost));
     float ms_primary = 0.0f;
     PT_HIP(ctx, hipEventElapsedTime(&ms_primary, sl.ev0, sl.evm));
+    if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] frame done: %.3f ms, workgroups wanted %u, other frames running at its start %u\n", ms, c.n_groups, c.others_running);
     ctx->stats.trace_ms = ms;
     ctx->stats.primary_ms = ms_primary;
     ctx->stats.paths_ms = ms - ms_primary;
@@ -1253,7 +1261,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             uint32_t* order = ctx->d_chunk_order.as<uint32_t>();
             ChunkOrderInfo* info = reinterpret_cast<ChunkOrderInfo*>(order + max_chunks);
             k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(w.cost, dc, fp.samples, ctx->d_chunk_bin.as<uint32_t>());
-            k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction);
+            k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction, ctx->group_margin_8ths[0], ctx->group_margin_8ths[1], ctx->n_cus);
             chunk_order = order;
             order_info = info;
         }

@@ -333,8 +333,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
 #ifndef PT_SPLIT_FRACTION
 #define PT_SPLIT_FRACTION 16u
 #endif
+// n_groups: how many workgroups of k_paths the frame can keep busy. A chunk's bin is its expected length (rounds of one
+// wave); the frame cannot end before its longest chunk does, so  margin x (sum of the lengths) / (longest length)  waves
+// finish it in about that time when the longest are started first, and more waves only hold LDS and wave slots that the
+// kernels of other frames in flight (other contexts, other streams) could use. Workgroups beyond n_groups leave at once.
+// The margin is tighter when such frames exist: g_frames_running counts the hint-ordered frames of this process whose
+// k_paths has not finished on this device (k_chunk_order signs a frame in, the last wave of its k_paths signs it off).
+// Short frames overlap only now and then even when the caller keeps several in flight, so the tighter margin stays in
+// use for PT_SHARED_MEMORY_TICKS of the constant 100 MHz clock after the last frame that did see another one.
+#define PT_SHARED_MEMORY_TICKS 2000000ull   // 20 ms
+__device__ uint32_t g_frames_running;
+__device__ unsigned long long g_last_shared_tick;
 struct ChunkOrderInfo {
-    uint32_t n_chunks, n_heavy, n_split, _pad;
+    uint32_t n_chunks, n_heavy, n_split, n_groups;
 };
 __global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__ cost, const DCounters* __restrict__ counters,
                                                     uint32_t samples, uint32_t* __restrict__ chunk_bin) {
@@ -351,8 +362,9 @@ __global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__
         chunk_bin[c] = bin < PT_COST_BINS ? (uint32_t)bin : PT_COST_BINS - 1u;
     }
 }
-__global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict__ chunk_bin, const DCounters* __restrict__ counters,
-                                                      uint32_t* __restrict__ order, ChunkOrderInfo* __restrict__ info, uint32_t split_fraction) {
+__global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict__ chunk_bin, DCounters* __restrict__ counters,
+                                                      uint32_t* __restrict__ order, ChunkOrderInfo* __restrict__ info, uint32_t split_fraction,
+                                                      uint32_t margin_alone_8ths, uint32_t margin_shared_8ths, uint32_t min_groups) {
     __shared__ uint32_t cnt[PT_COST_BINS], start[PT_COST_BINS];
     const uint32_t total = counters->n_paths;
     const uint32_t n_chunks = (total + PT_CHUNK - 1u) / PT_CHUNK;
@@ -362,10 +374,13 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0, heavy = 0, split = 0;
+        unsigned long long work = 0, longest = 0;   // in 1/8 rays per sample: a chunk of bin b takes about 8 + b
         bool top = true;
         for (int b = (int)PT_COST_BINS - 1; b >= 0; --b) {   // most expensive bin first
             start[b] = run;
             run += cnt[b];
+            work += (unsigned long long)cnt[b] * (8u + (uint32_t)b);
+            if (cnt[b] && !longest) longest = 8u + (uint32_t)b;
             if ((uint32_t)b >= PT_HEAVY_BIN) {
                 heavy = run;
                 if (top && run <= n_chunks / split_fraction) split = run; else if (cnt[b]) top = false;
@@ -374,7 +389,20 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
         info->n_chunks = n_chunks;
         info->n_heavy = heavy;
         info->n_split = split;
-        info->_pad = 0;
+        const uint32_t others = atomicAdd(&g_frames_running, 1u);
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        bool shared = others != 0u;
+        if (shared) atomicMax(&g_last_shared_tick, now);
+        else {
+            const unsigned long long last = atomicMax(&g_last_shared_tick, 0ull);
+            shared = last != 0ull && now - last < PT_SHARED_MEMORY_TICKS;
+        }
+        const uint32_t group_margin_8ths = shared ? margin_shared_8ths : margin_alone_8ths;
+        unsigned long long groups = 0xFFFFFFFFull;
+        if (group_margin_8ths && longest) groups = (work * group_margin_8ths / (8ull * longest) + 3ull) / 4ull;   // four waves each
+        info->n_groups = groups < min_groups ? min_groups : (groups > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)groups);
+        counters->n_groups = info->n_groups;
+        counters->others_running = others | (shared ? 0x100u : 0u);
     }
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024u) order[atomicAdd(&start[chunk_bin[c]], 1u)] = c;
@@ -430,6 +458,10 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                                                                     const ChunkOrderInfo* __restrict__ order_info,
                                                                     float4* __restrict__ out, uint32_t* __restrict__ aux_rays,
                                                                     DCounters* __restrict__ counters, uint4* __restrict__ wave_log) {
+    if (order_info && blockIdx.x >= order_info->n_groups) {   // more workgroups than the frame has work for
+        if (threadIdx.x == 0 && atomicAdd(&counters->waves_done, 4u) + 4u == 4u * gridDim.x) atomicSub(&g_frames_running, 1u);
+        return;
+    }
     PT_SCENE_VIEW_FROM_PARAMS()
     // [4 waves][stack_depth][64 lanes] stacks, [4 waves][lane_slots(MODE)][64 lanes], [4 waves][PT_SCHED_WORDS], staged scene
     constexpr uint32_t SLOTS = lane_slots(MODE);
@@ -573,11 +605,11 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                         sw_len = (sw_end - sw_begin) | (sw_end >= pp.samples ? 0x80000000u : 0u);
                         chunk_next = c * pp.chunk;
                         chunk_end = (total - chunk_next < pp.chunk) ? total : chunk_next + pp.chunk;
-                        if (part != PT_NONE) {
+                        solo = part != PT_NONE;   // (a part can be empty, the list's last chunk being short: the wave then goes on to another item)
+                        if (solo) {
                             const uint32_t len = pp.chunk / PT_SPLIT_PARTS;
                             chunk_next = min(chunk_next + part * len, chunk_end);
                             chunk_end = min(chunk_next + len, chunk_end);
-                            solo = true;
                         }
                         if (pp.n_sweeps > 1u && cpos >= n_heavy) report = c;
                         if (STATS) {
@@ -874,6 +906,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
 
     const uint32_t r = wave_sum_u32(lane_rays);
     if (lane == 0 && r) atomicAdd(&counters->rays, (unsigned long long)r);
+    if (order_info && lane == 0 && atomicAdd(&counters->waves_done, 1u) + 1u == 4u * gridDim.x) atomicSub(&g_frames_running, 1u);
 #ifdef PT_EXEC_COUNTS
     if (STATS) {
         for (int k = 0; k < 16; ++k) {

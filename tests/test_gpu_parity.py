@@ -546,6 +546,29 @@ def test_four_lanes_to_a_ray_changes_no_result(name, env, monkeypatch):
             assert ctx.check_accel()["errors"] == 0
 
 
+def test_split_chunks_with_a_short_last_chunk_at_1080p(monkeypatch):
+    """1080p frames of the glb scene at 16 spp with `time` advancing, on one context: from the second frame on the most
+    expensive chunks are handed out in parts. The path list's last chunk is short here (its fourth part is empty), the
+    case in which a wave goes on from an empty part to a whole chunk. Every frame must be the one the exhaustive loop
+    renders without any splitting, in every pixel and ray count."""
+    scene = scenes.scene_glb_textured(1920, 1080, 16, 10)
+    times = [0.5, 1.5, 2.5, 3.5]
+    want = []
+    with monkeypatch.context() as mp:
+        mp.setenv("PT_AMD_SPLIT_CHUNKS", "0")
+        with abi.Context(accel=abi.PT_ACCEL_BRUTE) as ctx:
+            ctx.upload_scene(scene)
+            for t in times:
+                want.append((ctx.render(scene.frame(time=t)).copy(), ctx.read_aux(abi.PT_AUX_RAY_COUNT).copy()))
+    for rep in range(2):
+        with abi.Context() as ctx:
+            ctx.upload_scene(scene)
+            for j, t in enumerate(times):
+                img = ctx.render(scene.frame(time=t))
+                assert np.array_equal(img.view(np.uint32), want[j][0].view(np.uint32)), f"pass {rep}, frame {j}"
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), want[j][1]), f"pass {rep}, frame {j}"
+
+
 def test_hints_from_another_view_change_no_result():
     """The schedule hints are taken from the context's previous frame even when the camera has moved since: the frame
     must be what a fresh context renders."""
