@@ -135,6 +135,8 @@ struct pt_ctx {
     std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
     bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
     uint64_t last_n_paths = ~0ull; // entries of the path list of the last frame read back
+    uint32_t last_waves_needed = 0; // its work over its longest chunk, in waves (0: it was not ordered by hints)
+    int list_regs = 0;             // object-list variants of k_paths: 0 chosen per frame, 1 always the build for four waves per SIMD, 2 always the roomy one
     uint32_t walk_quota = 16;     // see PathParams::walk_quota
     uint32_t blas_max_leaf = 2;   // triangles a BLAS leaf holds at most (1..PT_WIDE_MAX_LEAF); 2 measured best on the 968-triangle mesh of scene.glb
     bool carry_acquire = true;    // see PathParams::carry_acquire (costs about 1 % of a frame; PT_AMD_CARRY_ACQUIRE=0 leaves it out)
@@ -146,8 +148,9 @@ struct pt_ctx {
     uint32_t tlas_refits = 0;     // refits since that build
     bool tlas_refitted = false;   // the last object upload refitted
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
-    uint32_t split_fraction = PT_SPLIT_FRACTION;   // at most 1/this of the chunks are handed out in parts
-    uint32_t group_margin_8ths[2] = {12, 8};       // see ChunkOrderInfo::n_groups: waves = this/8 x work / longest chunk, {frame alone on the device, other frames running}; 0: always the whole grid
+    uint32_t split_fraction[2] = {PT_SPLIT_FRACTION_ALONE, PT_SPLIT_FRACTION};   // at most 1/this of the chunks are handed out in parts {frame alone on the device, other frames running}
+    uint32_t split_load_8ths = 16;                 // chunks are handed out in parts only while work / longest chunk <= this/8 x the waves of the launch; 0: always
+    uint32_t group_margin_8ths[2] = {24, 8};       // see ChunkOrderInfo::n_groups: waves = this/8 x work / longest chunk, {frame alone on the device, other frames running}; 0: always the whole grid
     bool blas_sah = true;         // BLAS of moderate meshes by the surface-area heuristic on the host (else Morton order)
     bool strict_hints = false;    // see render_enqueue
     bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
@@ -424,7 +427,14 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
             if (n == 1) b = a;
             if (n >= 1 && a >= 0 && a <= 4096 && b >= 0 && b <= 4096) { ctx->group_margin_8ths[0] = (uint32_t)a; ctx->group_margin_8ths[1] = (uint32_t)b; }
         }
-        if (const char* e = std::getenv("PT_AMD_SPLIT_FRACTION")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) ctx->split_fraction = (uint32_t)v; }
+        if (const char* e = std::getenv("PT_AMD_LIST_REGS")) ctx->list_regs = !std::strcmp(e, "roomy") ? 2 : !std::strcmp(e, "tight") ? 1 : 0;
+        if (const char* e = std::getenv("PT_AMD_SPLIT_LOAD")) { int v = std::atoi(e); if (v >= 0 && v <= 65536) ctx->split_load_8ths = (uint32_t)v; }
+        if (const char* e = std::getenv("PT_AMD_SPLIT_FRACTION")) {   // "alone,shared", or one number for both
+            int a = 0, b = 0;
+            const int n = std::sscanf(e, "%d,%d", &a, &b);
+            if (n == 1) b = a;
+            if (n >= 1 && a >= 1 && a <= 4096 && b >= 1 && b <= 4096) { ctx->split_fraction[0] = (uint32_t)a; ctx->split_fraction[1] = (uint32_t)b; }
+        }
         if (const char* e = std::getenv("PT_AMD_CARRY_ACQUIRE")) ctx->carry_acquire = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_BLAS_BUILDER")) ctx->blas_sah = std::strcmp(e, "lbvh") != 0;
         if (const char* e = std::getenv("PT_AMD_STRICT_HINTS")) ctx->strict_hints = std::atoi(e) != 0;
@@ -911,7 +921,7 @@ int finish_slot(pt_ctx* ctx, FrameSlot& sl) {
     PT_HIP(ctx, hipMemcpy(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost));
     float ms_primary = 0.0f;
     PT_HIP(ctx, hipEventElapsedTime(&ms_primary, sl.ev0, sl.evm));
-    if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] frame done: %.3f ms, workgroups wanted %u, other frames running at its start %u\n", ms, c.n_groups, c.others_running);
+    if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] frame done: %.3f ms, work / longest chunk %u waves, %u chunks in parts, workgroups wanted %u, other frames running at its start %u\n", ms, c.waves_needed, c.n_split, c.n_groups, c.others_running);
     ctx->stats.trace_ms = ms;
     ctx->stats.primary_ms = ms_primary;
     ctx->stats.paths_ms = ms - ms_primary;
@@ -938,6 +948,7 @@ int finish_slot(pt_ctx* ctx, FrameSlot& sl) {
     ctx->stats.lane_rounds = c.lane_rounds;
     ctx->stats.object_passes = c.passes;
     ctx->last_n_paths = c.n_paths;
+    ctx->last_waves_needed = c.waves_needed;
     ctx->stats.wave_life_sum = c.wave_life_sum;
     ctx->stats.wave_life_max = c.wave_life_max;
     ctx->stats.waves = c.waves;
@@ -1172,6 +1183,8 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
                                              {k_paths<PT_MODE_TLAS, false>, k_paths<PT_MODE_TLAS, true>},
                                              {k_paths<PT_MODE_LDS, false>, k_paths<PT_MODE_LDS, true>},
                                              {k_paths<PT_MODE_LIST_LB, false>, k_paths<PT_MODE_LIST_LB, true>}};
+        static const PathsFn ptable_roomy[4][2] = {{k_paths<PT_MODE_LIST, false, true>, k_paths<PT_MODE_LIST, true, true>}, {nullptr, nullptr}, {nullptr, nullptr},
+                                                   {k_paths<PT_MODE_LIST_LB, false, true>, k_paths<PT_MODE_LIST_LB, true, true>}};
         // Object-list scenes with a big mesh: its whole BLAS (and its triangles if they fit as well) goes into LDS,
         // at the price of fewer workgroups per compute unit. Rays in such a mesh are chains of dependent node
         // visits, each a round trip to the L2 otherwise.
@@ -1208,7 +1221,14 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             pp.tlas_top_n = std::min(ctx->tlas_n_wide, ctx->tlas_top_max == PT_NONE ? fit : ctx->tlas_top_max);
         }
         const size_t lds_paths = lds + (paths_mode == PT_MODE_LIST_LB ? lds_blas_bytes(lb.n_nodes, lb.n_tris) : 0u) + (size_t)pp.tlas_top_n * sizeof(WNode);
-        PathsFn fn = ptable[paths_mode][st ? 1 : 0];
+        // Object-list scenes whose last finished frame had work for few waves (the sum of its chunk lengths over the longest:
+        // see ChunkOrderInfo) run the build with twice the registers and half the waves per SIMD.
+        bool roomy = false;
+        if (paths_mode == PT_MODE_LIST || paths_mode == PT_MODE_LIST_LB) {
+            const uint64_t roomy_waves = (uint64_t)ctx->n_cus * 4u * PT_PATHS_MIN_WAVES_LIST_ROOMY;
+            roomy = ctx->list_regs == 2 || (ctx->list_regs == 0 && use_hint && ctx->last_waves_needed != 0u && (uint64_t)ctx->last_waves_needed <= 2u * roomy_waves);
+        }
+        PathsFn fn = (roomy ? ptable_roomy : ptable)[paths_mode][st ? 1 : 0];
         if (lds_paths > 64 * 1024) PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_paths));
         int per_cu = 0;
         PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds_paths));
@@ -1251,7 +1271,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             wlog = ctx->d_wave_log.as<uint4>();
             ctx->wave_log_records = grid * 4u;
         }
-        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d per_cu=%d grid=%u lds=%zu depth=%u/%u tlas: nodes=%u levels=%u need=%u top=%u chunk=%u refill_min=%u sweeps=%u last_n_paths=%llu\n", paths_mode, per_cu, grid, lds_paths, depth_paths, depth, ctx->tlas_n_wide, ctx->tlas_depth, ctx->tlas_need, pp.tlas_top_n, pp.chunk, pp.refill_min, pp.n_sweeps, (unsigned long long)ctx->last_n_paths);
+        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d roomy=%d per_cu=%d grid=%u lds=%zu depth=%u/%u tlas: nodes=%u levels=%u need=%u top=%u chunk=%u refill_min=%u sweeps=%u last_n_paths=%llu\n", paths_mode, (int)roomy, per_cu, grid, lds_paths, depth_paths, depth, ctx->tlas_n_wide, ctx->tlas_depth, ctx->tlas_need, pp.tlas_top_n, pp.chunk, pp.refill_min, pp.n_sweeps, (unsigned long long)ctx->last_n_paths);
         const uint32_t* chunk_order = nullptr;
         const ChunkOrderInfo* order_info = nullptr;
         if (use_hint && pp.chunk == PT_CHUNK) {
@@ -1261,7 +1281,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             uint32_t* order = ctx->d_chunk_order.as<uint32_t>();
             ChunkOrderInfo* info = reinterpret_cast<ChunkOrderInfo*>(order + max_chunks);
             k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(w.cost, dc, fp.samples, ctx->d_chunk_bin.as<uint32_t>());
-            k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction, ctx->group_margin_8ths[0], ctx->group_margin_8ths[1], ctx->n_cus);
+            k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction[0], ctx->split_fraction[1], ctx->group_margin_8ths[0], ctx->group_margin_8ths[1], ctx->n_cus, grid * 4u, ctx->split_load_8ths);
             chunk_order = order;
             order_info = info;
         }

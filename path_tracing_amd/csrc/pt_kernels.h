@@ -25,6 +25,13 @@
 #ifndef PT_PATHS_MIN_WAVES
 #define PT_PATHS_MIN_WAVES 4   // waves per SIMD k_paths is compiled for (caps its VGPR allocation)
 #endif
+#ifndef PT_PATHS_MIN_WAVES_LIST
+#define PT_PATHS_MIN_WAVES_LIST 4   // ... its object-list variants (PT_MODE_LIST, PT_MODE_LIST_LB)
+#endif
+// ... and their ROOMY builds: twice the registers per lane and half the waves per SIMD, for frames that are bound by a
+// few long chains of dependent rays and cannot fill more waves anyway (no register of the round lives in scratch memory,
+// and the compiler has room to overlap independent work within a lane)
+#define PT_PATHS_MIN_WAVES_LIST_ROOMY 2
 #ifndef PT_PATHS_MIN_WAVES_TLAS
 #define PT_PATHS_MIN_WAVES_TLAS 4   // ... its PT_MODE_TLAS variant
 #endif
@@ -320,8 +327,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
 #ifndef PT_HEAVY_BIN
 #define PT_HEAVY_BIN 2u   // chunks from this bin up (0.25 extra rays per sample) are run in one piece, first
 #endif
-// The most expensive chunks of all (whole cost bins from the top, at most 1/PT_SPLIT_FRACTION of the chunks) are handed
-// out in PT_SPLIT_PARTS parts of 16 entries, one part to a wave: their pixels are the longest chains of dependent rays of
+// The most expensive chunks of all (whole cost bins from the top, at most 1/PT_SPLIT_FRACTION of the chunks while other
+// frames run on the device, 1/PT_SPLIT_FRACTION_ALONE when the frame has the device to itself and idle lanes cost
+// nothing) are handed out in PT_SPLIT_PARTS parts of 16 entries, one part to a wave: their pixels are the longest chains of dependent rays of
 // the frame, and a round of a wave that traces for 16 lanes is much shorter than one for 64 (it lasts as long as its
 // slowest lane). The lanes left idle are affordable: those chains are what the rest of the chip ends up waiting for.
 #ifndef PT_SPLIT_PARTS
@@ -332,6 +340,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_primary(PT_SCENE_PARAMS, LdsScen
 #endif
 #ifndef PT_SPLIT_FRACTION
 #define PT_SPLIT_FRACTION 16u
+#endif
+#ifndef PT_SPLIT_FRACTION_ALONE
+#define PT_SPLIT_FRACTION_ALONE 4u
 #endif
 // n_groups: how many workgroups of k_paths the frame can keep busy. A chunk's bin is its expected length (rounds of one
 // wave); the frame cannot end before its longest chunk does, so  margin x (sum of the lengths) / (longest length)  waves
@@ -363,8 +374,9 @@ __global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__
     }
 }
 __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict__ chunk_bin, DCounters* __restrict__ counters,
-                                                      uint32_t* __restrict__ order, ChunkOrderInfo* __restrict__ info, uint32_t split_fraction,
-                                                      uint32_t margin_alone_8ths, uint32_t margin_shared_8ths, uint32_t min_groups) {
+                                                      uint32_t* __restrict__ order, ChunkOrderInfo* __restrict__ info, uint32_t split_fraction_alone, uint32_t split_fraction_shared,
+                                                      uint32_t margin_alone_8ths, uint32_t margin_shared_8ths, uint32_t min_groups,
+                                                      uint32_t launch_waves, uint32_t split_load_8ths) {
     __shared__ uint32_t cnt[PT_COST_BINS], start[PT_COST_BINS];
     const uint32_t total = counters->n_paths;
     const uint32_t n_chunks = (total + PT_CHUNK - 1u) / PT_CHUNK;
@@ -373,6 +385,19 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
     for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024u) atomicAdd(&cnt[chunk_bin[c]], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
+        // other frames on the device? (see g_frames_running)
+        const uint32_t others = atomicAdd(&g_frames_running, 1u);
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        bool shared = others != 0u;
+        if (shared) atomicMax(&g_last_shared_tick, now);
+        else {
+            const unsigned long long last = atomicMax(&g_last_shared_tick, 0ull);
+            shared = last != 0ull && now - last < PT_SHARED_MEMORY_TICKS;
+        }
+        const uint32_t split_fraction = shared ? split_fraction_shared : split_fraction_alone;
+        const uint32_t group_margin_8ths = shared ? margin_shared_8ths : margin_alone_8ths;
+        // (and no more parts than one and a half times the waves of the launch: beyond that they only queue up)
+        const uint32_t split_limit = min(n_chunks / split_fraction, launch_waves * 3u / (2u * PT_SPLIT_PARTS));
         uint32_t run = 0, heavy = 0, split = 0;
         unsigned long long work = 0, longest = 0;   // in 1/8 rays per sample: a chunk of bin b takes about 8 + b
         bool top = true;
@@ -383,25 +408,22 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
             if (cnt[b] && !longest) longest = 8u + (uint32_t)b;
             if ((uint32_t)b >= PT_HEAVY_BIN) {
                 heavy = run;
-                if (top && run <= n_chunks / split_fraction) split = run; else if (cnt[b]) top = false;
+                if (top && run <= split_limit) split = run; else if (cnt[b]) top = false;
             }
         }
+        // Parts leave three lanes in four idle: worth it while the launch has waves to spare, i.e. while the frame is bound
+        // by its longest chains; a frame with several times more work than the launch has waves is bound by throughput.
+        const unsigned long long waves_needed = longest ? work / longest : 0ull;
+        if (split_load_8ths && waves_needed * 8ull > (unsigned long long)launch_waves * split_load_8ths) split = 0;
         info->n_chunks = n_chunks;
         info->n_heavy = heavy;
         info->n_split = split;
-        const uint32_t others = atomicAdd(&g_frames_running, 1u);
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        bool shared = others != 0u;
-        if (shared) atomicMax(&g_last_shared_tick, now);
-        else {
-            const unsigned long long last = atomicMax(&g_last_shared_tick, 0ull);
-            shared = last != 0ull && now - last < PT_SHARED_MEMORY_TICKS;
-        }
-        const uint32_t group_margin_8ths = shared ? margin_shared_8ths : margin_alone_8ths;
         unsigned long long groups = 0xFFFFFFFFull;
         if (group_margin_8ths && longest) groups = (work * group_margin_8ths / (8ull * longest) + 3ull) / 4ull;   // four waves each
         info->n_groups = groups < min_groups ? min_groups : (groups > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)groups);
         counters->n_groups = info->n_groups;
+        counters->waves_needed = (uint32_t)waves_needed;
+        counters->n_split = split;
         counters->others_running = others | (shared ? 0x100u : 0u);
     }
     __syncthreads();
@@ -451,8 +473,8 @@ __host__ __device__ constexpr uint32_t lane_slots(int mode) { return mode == PT_
 #define PT_SCHED_LEN 6       // its number of samples; bit 31: it ends the pixel
 #define PT_SCHED_WORDS 8
 
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS : PT_PATHS_MIN_WAVES) void k_paths(PT_SCENE_PARAMS, LdsScene ls, LdsBlas lb, PathParams pp, uint32_t stack_depth,
+template <int MODE, bool STATS, bool ROOMY = false>
+__global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS : MODE == PT_MODE_LDS ? PT_PATHS_MIN_WAVES : ROOMY ? PT_PATHS_MIN_WAVES_LIST_ROOMY : PT_PATHS_MIN_WAVES_LIST) void k_paths(PT_SCENE_PARAMS, LdsScene ls, LdsBlas lb, PathParams pp, uint32_t stack_depth,
                                                                     const PathRec* __restrict__ recs, PathCarry* __restrict__ carry,
                                                                     uint32_t* __restrict__ sweeps_done, const uint32_t* __restrict__ chunk_order,
                                                                     const ChunkOrderInfo* __restrict__ order_info,

@@ -193,5 +193,5 @@ struct DCounters {
     unsigned long long cyc_refill, cyc_trace, cyc_shade, rounds, lane_rounds, wave_life_sum, wave_life_max, waves;
     unsigned int life_hist[32];   // histogram of k_paths wave lifetimes, 2^19 cycles per bucket (STATS only)
     unsigned int waves_done;      // k_paths waves that have left (kept only for frames ordered by hints; the last one signs the frame off)
-    unsigned int n_groups, others_running;   // what k_chunk_order decided and saw (for logs)
+    unsigned int n_groups, others_running, waves_needed, n_split;   // what k_chunk_order decided and saw (for logs)
 };

@@ -461,7 +461,8 @@ def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
     run(3)   # (the glb scene: from the second frame on its big mesh's BLAS is staged in LDS)
     for env in ({"PT_AMD_SWEEPS": "1"}, {"PT_AMD_SWEEPS": "8"}, {"PT_AMD_NO_COST_HINTS": "1"}, {"PT_AMD_REFILL_MIN": "1"},
                 {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}, {"PT_AMD_NO_LDS_BLAS": "1"}, {"PT_AMD_WALK_QUOTA": "1"}, {"PT_AMD_WALK_QUOTA": "64"},
-                {"PT_AMD_SPLIT_CHUNKS": "0"}, {"PT_AMD_SPLIT_CHUNKS": "0", "PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_SPLIT_CHUNKS": "1", "PT_AMD_NO_LDS_SCENE": "1"}):
+                {"PT_AMD_SPLIT_CHUNKS": "0"}, {"PT_AMD_SPLIT_CHUNKS": "0", "PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_SPLIT_CHUNKS": "1", "PT_AMD_NO_LDS_SCENE": "1"},
+                {"PT_AMD_LIST_REGS": "roomy", "PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_LIST_REGS": "roomy", "PT_AMD_SPLIT_FRACTION": "1", "PT_AMD_SPLIT_LOAD": "0"}):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
@@ -560,13 +561,18 @@ def test_split_chunks_with_a_short_last_chunk_at_1080p(monkeypatch):
             ctx.upload_scene(scene)
             for t in times:
                 want.append((ctx.render(scene.frame(time=t)).copy(), ctx.read_aux(abi.PT_AUX_RAY_COUNT).copy()))
-    for rep in range(2):
-        with abi.Context() as ctx:
-            ctx.upload_scene(scene)
-            for j, t in enumerate(times):
-                img = ctx.render(scene.frame(time=t))
-                assert np.array_equal(img.view(np.uint32), want[j][0].view(np.uint32)), f"pass {rep}, frame {j}"
-                assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), want[j][1]), f"pass {rep}, frame {j}"
+    # (the defaults twice; then the kernel build for four waves per SIMD where the default picks the one with more registers
+    # for such a frame, every heavy chunk in parts, and as few workgroups as the library ever keeps)
+    for env in ({}, {}, {"PT_AMD_LIST_REGS": "tight"}, {"PT_AMD_SPLIT_FRACTION": "1", "PT_AMD_SPLIT_LOAD": "0"}, {"PT_AMD_GROUP_MARGIN": "1"}):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            with abi.Context() as ctx:
+                ctx.upload_scene(scene)
+                for j, t in enumerate(times):
+                    img = ctx.render(scene.frame(time=t))
+                    assert np.array_equal(img.view(np.uint32), want[j][0].view(np.uint32)), f"{env}, frame {j}"
+                    assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), want[j][1]), f"{env}, frame {j}"
 
 
 def test_hints_from_another_view_change_no_result():
