@@ -928,7 +928,8 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
 
     const uint32_t r = wave_sum_u32(lane_rays);
     if (lane == 0 && r) atomicAdd(&counters->rays, (unsigned long long)r);
-    if (order_info && lane == 0 && atomicAdd(&counters->waves_done, 1u) + 1u == 4u * gridDim.x) atomicSub(&g_frames_running, 1u);
+    // (chunk_order and order_info come together; the former is in use all through the loop anyway)
+    if (chunk_order && lane == 0 && atomicAdd(&counters->waves_done, 1u) + 1u == 4u * gridDim.x) atomicSub(&g_frames_running, 1u);
 #ifdef PT_EXEC_COUNTS
     if (STATS) {
         for (int k = 0; k < 16; ++k) {

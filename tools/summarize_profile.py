@@ -22,8 +22,8 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def is_stats_variant(name):
-    """k_primary<MODE, true> / k_paths<MODE, true>: the instrumented builds used for the work counters."""
-    return re.search(r"<\d+, true>", name.split("(")[0]) is not None
+    """k_primary<MODE, true, ...> / k_paths<MODE, true, ...>: the instrumented builds used for the work counters."""
+    return re.search(r"<\d+, true[,>]", name.split("(")[0]) is not None
 
 
 def read_counters(d, kernel):
