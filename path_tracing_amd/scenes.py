@@ -326,6 +326,41 @@ def scene_glb_textured(width=1920, height=1080, samples=256, bounces=10) -> Scen
                    width=width, height=height, samples=samples, bounces=bounces)
 
 
+def overlapping_meshes(width=256, height=144, samples=16, bounces=8) -> Scene:
+    """Synthetic (not one of the reference's scenes): twelve objects (the most that still get the object list rather than a TLAS): bumpy sheets with a BLAS, thin strips,
+    cubes without one, two of the sheets coincident so that equal distances occur; boxes overlap heavily."""
+    rng = np.random.default_rng(5)
+    b = SceneBuilder()
+    n = 24
+    x = np.linspace(-1.0, 1.0, n + 1)
+    xx, zz = np.meshgrid(x, x, indexing="ij")
+    yy = 0.2 * np.sin(5 * xx) * np.cos(4 * zz)
+    pos = np.stack([xx, yy, zz], axis=-1).reshape(-1, 3)
+    nrm = np.tile(np.array([0.0, 1.0, 0.0]), (len(pos), 1))
+    uv = np.stack([(xx + 1) / 2, (zz + 1) / 2], axis=-1).reshape(-1, 2)
+    idx = []
+    for i in range(n):
+        for j in range(n):
+            a, bb, c, d = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
+            idx += [a, d, bb, bb, d, c]
+    sheet = b.add_mesh(pos, nrm, uv, np.array(idx))                      # 1,152 triangles
+    strip = b.add_mesh(pos[: 2 * (n + 1)], nrm[: 2 * (n + 1)], uv[: 2 * (n + 1)], np.array(idx[: 6 * n]))   # 48 triangles
+    cube = b.add_mesh(*cube_mesh(1.0))
+    mats = [b.add_material(albedo=tuple(rng.uniform(0.3, 0.9, 3)), roughness=float(r)) for r in (0.0, 0.4, 1.0, 0.7)]
+    light = b.add_material(albedo=(0, 0, 0), emissive=(6, 6, 6))
+    S = lambda sx, sy, sz: np.diag([sx, sy, sz, 1.0])
+    b.add_object(sheet, mats[0], S(3, 1, 3))
+    b.add_object(sheet, mats[1], S(3, 1, 3))                                   # coincident with the first
+    b.add_object(sheet, mats[2], translation(0, 0.6, 0) @ rotation_x(0.5) @ S(2, 1, 2))
+    b.add_object(sheet, mats[3], translation(0.3, 1.0, -0.5) @ rotation_z(-0.7) @ S(1.5, 2, 1.5))
+    for k in range(3):
+        b.add_object(strip, mats[k], translation(0.4 * k - 0.4, 0.5 + 0.3 * k, 0.2 * k) @ rotation_y(0.9 * k) @ S(2, 1, 6))
+    for k in range(4):
+        b.add_object(cube, mats[k], translation(*rng.uniform(-1.2, 1.2, 3)) @ rotation_y(float(rng.uniform(0, 3))) @ S(0.5, 0.5 + 0.3 * k, 0.5))
+    b.add_object(cube, light, translation(0.5, 2.6, 0.8) @ S(0.6, 0.2, 0.6))
+    return b.build("overlap", Camera((1.5, 2.4, 4.5), (0, 0.5, 0)), sky_color=(0.25, 0.3, 0.4), width=width, height=height, samples=samples, bounces=bounces)
+
+
 def instanced_boxes(n_objects=83334, width=1920, height=1080, samples=256, bounces=10, seed=0x5EED0001,
                     extent=40.0) -> Scene:
     """One 12-triangle cube mesh instanced `n_objects` times (83,334 -> 1,000,008 triangles) with seeded random

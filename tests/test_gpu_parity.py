@@ -469,41 +469,6 @@ def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
             run(2)
 
 
-def overlapping_meshes_list_scene():
-    """Twelve objects (the most that still get the object list rather than a TLAS): bumpy sheets with a BLAS, thin strips,
-    cubes without one, two of the sheets coincident so that equal distances occur; boxes overlap heavily."""
-    rng = np.random.default_rng(5)
-    b = scenes.SceneBuilder()
-    n = 24
-    x = np.linspace(-1.0, 1.0, n + 1)
-    xx, zz = np.meshgrid(x, x, indexing="ij")
-    yy = 0.2 * np.sin(5 * xx) * np.cos(4 * zz)
-    pos = np.stack([xx, yy, zz], axis=-1).reshape(-1, 3)
-    nrm = np.tile(np.array([0.0, 1.0, 0.0]), (len(pos), 1))
-    uv = np.stack([(xx + 1) / 2, (zz + 1) / 2], axis=-1).reshape(-1, 2)
-    idx = []
-    for i in range(n):
-        for j in range(n):
-            a, bb, c, d = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
-            idx += [a, d, bb, bb, d, c]
-    sheet = b.add_mesh(pos, nrm, uv, np.array(idx))                      # 1,152 triangles
-    strip = b.add_mesh(pos[: 2 * (n + 1)], nrm[: 2 * (n + 1)], uv[: 2 * (n + 1)], np.array(idx[: 6 * n]))   # 48 triangles
-    cube = b.add_mesh(*scenes.cube_mesh(1.0))
-    mats = [b.add_material(albedo=tuple(rng.uniform(0.3, 0.9, 3)), roughness=float(r)) for r in (0.0, 0.4, 1.0, 0.7)]
-    light = b.add_material(albedo=(0, 0, 0), emissive=(6, 6, 6))
-    S = lambda sx, sy, sz: np.diag([sx, sy, sz, 1.0])
-    b.add_object(sheet, mats[0], S(3, 1, 3))
-    b.add_object(sheet, mats[1], S(3, 1, 3))                                   # coincident with the first
-    b.add_object(sheet, mats[2], scenes.translation(0, 0.6, 0) @ scenes.rotation_x(0.5) @ S(2, 1, 2))
-    b.add_object(sheet, mats[3], scenes.translation(0.3, 1.0, -0.5) @ scenes.rotation_z(-0.7) @ S(1.5, 2, 1.5))
-    for k in range(3):
-        b.add_object(strip, mats[k], scenes.translation(0.4 * k - 0.4, 0.5 + 0.3 * k, 0.2 * k) @ scenes.rotation_y(0.9 * k) @ S(2, 1, 6))
-    for k in range(4):
-        b.add_object(cube, mats[k], scenes.translation(*rng.uniform(-1.2, 1.2, 3)) @ scenes.rotation_y(float(rng.uniform(0, 3))) @ S(0.5, 0.5 + 0.3 * k, 0.5))
-    b.add_object(cube, light, scenes.translation(0.5, 2.6, 0.8) @ S(0.6, 0.2, 0.6))
-    return b.build("overlap", scenes.Camera((1.5, 2.4, 4.5), (0, 0.5, 0)), sky_color=(0.25, 0.3, 0.4), width=256, height=144, samples=16, bounces=8)
-
-
 @pytest.mark.parametrize("name,env", [
     ("glb", {}),                                   # object list, the big mesh's BLAS staged in LDS
     ("glb", {"PT_AMD_NO_LDS_BLAS": "1"}),          # object list, every BLAS in global memory
@@ -521,7 +486,7 @@ def test_four_lanes_to_a_ray_changes_no_result(name, env, monkeypatch):
     elif name == "boxes":
         scene, rect = scenes.boxes(320, 180, 16, 10), (150, 80, 182, 104)
     else:
-        scene, rect = overlapping_meshes_list_scene(), (120, 64, 144, 80)
+        scene, rect = scenes.overlapping_meshes(), (120, 64, 144, 80)
     frame = scene.frame()
     want = render_all(scene, frame, abi.PT_ACCEL_BRUTE)
     ref = oracle_render(scene, frame, rect=rect)
