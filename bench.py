@@ -11,8 +11,8 @@ with one RCCL all-reduce per step: N x 64 spp per step, per-GPU work fixed (weak
 `--multi-gpu tiles` instead splits the 8x8 tiles of ONE frame over the ranks (all-reduce = gather, image
 bit-identical to the one-GPU image, strong scaling).
 
-Frames are kept in flight (--frames-in-flight, default 3): that many contexts take the frames in turn on their own
-streams, so the start of a frame overlaps the tail of the previous one; results are those of one context.
+Frames are kept in flight (--frames-in-flight, default 3; 5 and 4 for the two workloads whose frames are chains of few
+pixels, cornell and scene_glb_textured): that many contexts take the frames in turn on their own streams, so the start of a frame overlaps the tail of the previous one; results are those of one context.
 
 Every step is a new frame the way the reference makes one (src/raytrace.wgsl:210, src/extract.rs:297-346): `time`
 advances, so every pixel draws new random numbers, and the object array is handed over again (unchanged, as the example
@@ -37,9 +37,10 @@ import numpy as np
 
 # Frames in flight run on separate HIP streams; they only overlap on the GPU if each stream gets a hardware queue of
 # its own. HIP's default of 4 queues per process is shared with the contexts' upload streams, torch's streams and
-# RCCL's, so ask for 8 (read by the runtime when it initialises, i.e. before torch is imported).
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# RCCL's; with 8 a kernel trace still showed the fourth of four frame streams on the third one's queue, with 16 up to
+# six streams ran side by side (read by the runtime when it initialises, i.e. before torch is imported).
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -73,6 +74,11 @@ WORKLOADS = {
     "instanced_boxes": ("83,334 instanced cubes (1,000,008 triangles), 1920x1080, 256 spp", lambda: scenes.instanced_boxes(83334, 1920, 1080, 256, 10)),
     "cornell_4k": ("Cornell box 3840x2160, 4096 spp", lambda: scenes.cornell_4k(4096)),
 }
+
+
+# Frames kept in flight by default (ms per frame at 3 / 4 / 5 / 6 with 16 hardware queues: boxes 1.52 / 1.60 / 1.63 / 1.59,
+# cornell 0.466 / 0.433 / 0.413 / 0.412, scene_glb_textured 11.0 / 10.7 / 10.9 / 11.1)
+FRAMES_IN_FLIGHT = {"cornell": 5, "scene_glb_textured": 4}
 
 
 def virtual_frame_time(rank: int) -> float:
@@ -112,7 +118,8 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (invalidates the headline config)")
     ap.add_argument("--cpu-spp", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="contexts that take the frames in turn (1: strictly one frame at a time)")
+    ap.add_argument("--frames-in-flight", type=int, default=None, help="contexts that take the frames in turn (1: strictly one frame at a time); "
+                    "default: 3, for the workloads whose frames are chains of few pixels what measured best (cornell 5, scene_glb_textured 4)")
     ap.add_argument("--repeats", type=int, default=10, help="times the K-step timed region is run (median and minimum are reported); "
                     "cut down so that the repeats of one timing take about 8 s at most")
     ap.add_argument("--only-timed", action="store_true", help="stop after the timed region and print a short line (for profiler passes: "
@@ -161,7 +168,7 @@ def main():
     # the frames in turn, so the tail of one frame's path kernel (waves running out of work) is filled by the
     # start of the next frame. For N > 1 the all-reduce of a frame runs on one more stream while later frames are
     # traced. Every frame and every reduction is complete before the closing synchronize of the timed region.
-    F = max(1, args.frames_in_flight)
+    F = max(1, args.frames_in_flight if args.frames_in_flight is not None else FRAMES_IN_FLIGHT.get(args.workload, 3))
     ctxs = [abi.Context(device=local_rank) for _ in range(F)]
     for c in ctxs:
         c.upload_scene(scene)
