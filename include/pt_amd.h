@@ -222,7 +222,13 @@ int pt_render(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_host);
  * the call returns after enqueueing on `hip_stream` (a hipStream_t, or NULL for
  * the context's own stream, in which case the call synchronises before
  * returning). Used by callers that keep the image on the GPU (multi-GPU
- * reduce/gather, on-device post-processing). */
+ * reduce/gather, on-device post-processing), and by callers that overlap frames:
+ * several contexts with the same scene, each on a stream of its own, taking the
+ * frames in turn. The library sees on the device whether other frames of the
+ * process are running and schedules a frame for throughput then (only as many
+ * workgroups as it has work for, fewer of its pixels handed out in small
+ * portions) and for latency when it has the device to itself; the image does not
+ * depend on the schedule. */
 int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
                      void* hip_stream);
 
