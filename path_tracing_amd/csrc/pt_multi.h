@@ -38,14 +38,20 @@ bool rccl_load() {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.ok) return true;
     if (g_rccl.lib) return false;   // tried before
-    const char* names[] = {std::getenv("PT_AMD_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // PT_AMD_RCCL_LIBRARY, when set, is the only file tried
+    const char* named = std::getenv("PT_AMD_RCCL_LIBRARY");
+    const bool only_named = named && *named;
+    const char* names[] = {named, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why = "not found";
     for (const char* n : names) {
-        if (!n || !*n) continue;
+        if (!n || !*n || (only_named && n != named)) continue;
         g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.lib) break;
+        const char* e = dlerror();   // (one call: it hands the message out once and then returns null)
+        if (e) why = e;
     }
     if (!g_rccl.lib) {
-        g_rccl.error = std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "not found");
+        g_rccl.error = "librccl could not be opened: " + why;
         g_rccl.lib = reinterpret_cast<void*>(1);
         return false;
     }

@@ -59,6 +59,21 @@ def test_numpy_layouts_match_reference_offsets():
                                "metallic_roughness_texture", "reflectance", "normal_map_texture")] == [12, 16, 28, 32, 36, 40, 44, 48]
 
 
+def test_a_collective_library_that_cannot_be_opened_is_reported():
+    """PT_AMD_RCCL_LIBRARY names the only file tried; a failure comes back as PT_ERR_UNSUPPORTED with the loader's message
+    (one process per case: the library is opened once per process)."""
+    import os, sys
+    code = ("from path_tracing_amd import abi\n"
+            "try:\n    abi.rccl_version()\n    print('opened')\n"
+            "except abi.PtError as e:\n    print('error', e.code, str(e))\n")
+    env = dict(os.environ, PT_AMD_RCCL_LIBRARY="/nonexistent/librccl-missing.so")
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.strip()
+    assert out.startswith("error"), out
+    assert str(abi.PT_ERR_UNSUPPORTED) in out and "could not be opened" in out and "librccl-missing" in out, out
+
+
 def test_pt_create_error_paths_without_device(lib):
     h = C.c_void_p()
     assert lib.pt_create(None, C.byref(h)) == abi.PT_ERR_INVALID_ARGUMENT
