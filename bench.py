@@ -252,6 +252,17 @@ def main():
     for k in range(F):
         ctxs[k].render_device(frame, bufs[k].data_ptr(), streams[k].cuda_stream)
     torch.cuda.synchronize(device)
+    if world > 1:
+        # one untimed reduction of a full-size image: the collective library sets up its channels and buffers at the first
+        # call, which must not fall into the timed region when the caller asks for no warm-up steps
+        with torch.cuda.stream(comm_stream):
+            if args.backend == "nccl":
+                dist.all_reduce(bufs[0], op=dist.ReduceOp.SUM)
+            else:
+                host = bufs[0].cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        comm_stream.synchronize()
+        dist.barrier()
 
     # detailed work counters from one untimed pass (slower kernel variant)
     ctx.set_stats_detail(True)
