@@ -12,15 +12,21 @@ with one RCCL all-reduce per step: N x 64 spp per step, per-GPU work fixed (weak
 bit-identical to the one-GPU image, strong scaling).
 
 Frames are kept in flight (--frames-in-flight, default 3; 5 and 4 for the two workloads whose frames are chains of few
-pixels, cornell and scene_glb_textured): that many contexts take the frames in turn on their own streams, so the start of a frame overlaps the tail of the previous one; results are those of one context.
+pixels, cornell and scene_glb_textured) on ONE context: pt_render_submit_device on that many slots in turn, pt_render_wait
+on a slot before it is reused, so the start of a frame overlaps the tail of the previous one over one copy of the scene.
+(N > 1 ranks, whose frames are followed by a collective on a stream of torch's, use one context per frame in flight with
+pt_render_device on torch streams instead; `ms_per_step_contexts` times that arrangement on one GPU as well.)
 
 Every step is a new frame the way the reference makes one (src/raytrace.wgsl:210, src/extract.rs:297-346): `time`
 advances, so every pixel draws new random numbers, and the object array is handed over again (unchanged, as the example
 scenes are static). The timed region of K steps is repeated (--repeats, fewer for workloads of seconds per repeat);
-`value` and `ms_per_step` are the median repeat, the fastest one is reported beside it. Three more timings of the same K
-steps are reported: one frame at a time on one context (what a caller of the synchronous pt_render sees, without the
-copy to the host), with a camera that swings about the view target by up to 0.002 rad per frame (the schedule hints then
-come from a slightly different view), and with the hints switched off (what the first frame after a cut gets).
+`value` and `ms_per_step` are the median repeat, the fastest one is reported beside it. More timings of the same K
+steps are reported: one frame at a time (one slot), with a camera that swings about the view target by up to 0.002 rad
+per frame (the schedule hints then come from a slightly different view), with the hints switched off (what the first
+frame after a cut gets), and what the plugin gets through the boundary as INTEGRATION.md shows it, image delivered to
+page-locked host memory as binary16 each frame: synchronously (`ms_per_step_plugin_sync`: pt_render) and with frames in
+flight (`ms_per_step_plugin_async`: pt_render_submit / pt_render_wait); and the headline arrangement in a process that
+leaves HIP's hardware-queue count at its default (`ms_per_step_default_hw_queues`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -29,6 +35,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -39,7 +46,8 @@ import numpy as np
 # its own. HIP's default of 4 queues per process is shared with the contexts' upload streams, torch's streams and
 # RCCL's; with 8 a kernel trace still showed the fourth of four frame streams on the third one's queue, with 16 up to
 # six streams ran side by side (read by the runtime when it initialises, i.e. before torch is imported).
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
+# --default-hw-queues leaves the variable alone (the child process behind `ms_per_step_default_hw_queues`).
+if "--default-hw-queues" not in sys.argv and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
     os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 ROOT = Path(__file__).resolve().parent
@@ -128,6 +136,9 @@ def main():
     ap.add_argument("--multi-gpu", default="virtual_frames", choices=["virtual_frames", "tiles"],
                     help="N > 1: every GPU renders its own virtual frame (N x spp, weak scaling) or a share of the tiles of one frame (strong scaling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path with every rank on GPU 0")
+    ap.add_argument("--default-hw-queues", action="store_true", help="do not raise GPU_MAX_HW_QUEUES (HIP's default is 4 hardware queues per process)")
+    ap.add_argument("--contexts", action="store_true", help="one GPU: keep the frames in flight on one context each (pt_render_device on torch "
+                    "streams) instead of on the slots of one context")
     args = ap.parse_args()
 
     import torch
@@ -164,12 +175,16 @@ def main():
         frame = scene.frame(time=virtual_frame_time(rank))
     W, H = frame.width, frame.height
 
-    # Frames in flight: F contexts (the scene arrays are small), each with its own stream and image buffer, take
-    # the frames in turn, so the tail of one frame's path kernel (waves running out of work) is filled by the
-    # start of the next frame. For N > 1 the all-reduce of a frame runs on one more stream while later frames are
-    # traced. Every frame and every reduction is complete before the closing synchronize of the timed region.
+    # Frames in flight. One GPU: ONE context, F slots (pt_render_submit_device / pt_render_wait), one copy of the scene;
+    # the tail of one frame's path kernel (waves running out of work) is filled by the start of the next frame.
+    # N > 1 (or --contexts): F contexts, each with its own torch stream and image buffer, take the frames in turn, and the
+    # all-reduce of a frame runs on one more stream while later frames are traced. Every frame and every reduction is
+    # complete before the closing synchronize of the timed region.
     F = max(1, args.frames_in_flight if args.frames_in_flight is not None else FRAMES_IN_FLIGHT.get(args.workload, 3))
-    ctxs = [abi.Context(device=local_rank) for _ in range(F)]
+    if F > abi.PT_MAX_FRAME_SLOTS:
+        raise SystemExit(f"--frames-in-flight: at most {abi.PT_MAX_FRAME_SLOTS}")
+    use_slots = world == 1 and not args.contexts
+    ctxs = [abi.Context(device=local_rank) for _ in range(1 if use_slots else F)]
     for c in ctxs:
         c.upload_scene(scene)
     ctx = ctxs[0]
@@ -180,6 +195,8 @@ def main():
     comm_stream = torch.cuda.Stream(device) if world > 1 else None
     rendered = [torch.cuda.Event() for _ in bufs]
     reduced = [torch.cuda.Event() for _ in bufs]
+    comm_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in bufs]
+    comm_ms = []
     step_no = [0]
 
     frames = [scene.frame(time=virtual_frame_time(rank), part_index=rank, part_count=world) if tiles else scene.frame(time=virtual_frame_time(rank))
@@ -215,42 +232,117 @@ def main():
         elif orbit_views:
             fr.world_from_view = orbit_views[160]
 
-    def step(cs=None, one_at_a_time=False):
-        cs = cs or ctxs
-        n = len(cs)
-        i = step_no[0]
-        k = i % n
-        step_no[0] += 1
-        buf = bufs[k]
-        fr = frames[k]
-        fr.time = frame_time(i)
-        set_view(fr, i)
-        cs[k].upload_objects(scene.objects)      # extract_visible hands the objects over every frame; unchanged here
-        if world == 1:
-            cs[k].render_device(fr, buf.data_ptr(), streams[k].cuda_stream)
-            if one_at_a_time:
-                streams[k].synchronize()
-            return
-        streams[k].wait_event(reduced[k])        # this buffer's previous reduction (F steps ago) has finished
-        cs[k].render_device(fr, buf.data_ptr(), streams[k].cuda_stream)
-        rendered[k].record(streams[k])
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(rendered[k])
-            if args.backend == "nccl":
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            else:
-                host = buf.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                buf.copy_(host)
-            if not tiles:
-                buf.mul_(1.0 / world)
-            reduced[k].record(comm_stream)
-        if one_at_a_time:
-            comm_stream.synchronize()
+    class Slots:
+        """K frames in flight on the slots of one context; `host`: K page-locked arrays the images are copied into
+        (the plugin's path), else they stay in `bufs` on the device."""
 
-    # one untimed frame per context: allocations, and the ray counts the next frame's schedule is derived from
+        def __init__(self, c, k, host=None, f16=False):
+            self.c, self.k, self.host = c, k, host
+            self.busy = [False] * k
+            self.flags = abi.PT_FRAME_OUTPUT_F16 if f16 else 0
+
+        def step(self):
+            i = step_no[0]
+            s = i % self.k
+            step_no[0] += 1
+            if self.busy[s]:
+                self.c.wait(s)
+            fr = frames[s]
+            fr.time = frame_time(i)
+            fr.flags = self.flags
+            set_view(fr, i)
+            self.c.upload_objects(scene.objects)      # extract_visible hands the objects over every frame; unchanged here
+            if self.host is not None:
+                self.c.submit(fr, s, self.host[s])
+            else:
+                self.c.submit_device(fr, s, bufs[s].data_ptr())
+            self.busy[s] = True
+
+        def drain(self):
+            for s in range(self.k):
+                if self.busy[s]:
+                    self.c.wait(s)
+                    self.busy[s] = False
+            for fr in frames:
+                fr.flags = 0
+
+    class Contexts:
+        """One context per frame in flight, pt_render_device on a torch stream each; for N > 1 followed by the collective."""
+
+        def __init__(self, cs):
+            self.cs = cs
+
+        def step(self):
+            cs = self.cs
+            n = len(cs)
+            i = step_no[0]
+            k = i % n
+            step_no[0] += 1
+            buf = bufs[k]
+            fr = frames[k]
+            fr.time = frame_time(i)
+            set_view(fr, i)
+            cs[k].upload_objects(scene.objects)
+            if world == 1:
+                cs[k].render_device(fr, buf.data_ptr(), streams[k].cuda_stream)
+                return
+            streams[k].wait_event(reduced[k])        # this buffer's previous reduction (F steps ago) has finished
+            cs[k].render_device(fr, buf.data_ptr(), streams[k].cuda_stream)
+            rendered[k].record(streams[k])
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(rendered[k])
+                comm_ev[k][0].record(comm_stream)
+                if args.backend == "nccl":
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                else:
+                    host = buf.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    buf.copy_(host)
+                if not tiles:
+                    buf.mul_(1.0 / world)
+                comm_ev[k][1].record(comm_stream)
+                reduced[k].record(comm_stream)
+
+        def drain(self):
+            torch.cuda.synchronize(device)
+            if world > 1:   # device time of the last reductions (events on the collective's stream), for comm_ms_per_step
+                for a, b in comm_ev[:len(self.cs)]:
+                    try:
+                        comm_ms.append(a.elapsed_time(b))
+                    except Exception:
+                        pass
+
+    class PluginSync:
+        """What INTEGRATION.md's replacement of RayTraceNode::run does: one synchronous pt_render per frame, binary16
+        image into page-locked host memory."""
+
+        def __init__(self, c, host):
+            self.c, self.host = c, host
+
+        def step(self):
+            i = step_no[0]
+            step_no[0] += 1
+            fr = frames[0]
+            fr.time = frame_time(i)
+            fr.flags = abi.PT_FRAME_OUTPUT_F16
+            set_view(fr, i)
+            self.c.upload_objects(scene.objects)
+            self.c.render(fr, out=self.host)
+
+        def drain(self):
+            frames[0].flags = 0
+
+    runner = Slots(ctx, F) if use_slots else Contexts(ctxs)
+
+    # one untimed frame per slot / context: allocations, and the ray counts the next frame's schedule is derived from
     for k in range(F):
-        ctxs[k].render_device(frame, bufs[k].data_ptr(), streams[k].cuda_stream)
+        if use_slots:
+            ctx.submit_device(frame, k, bufs[k].data_ptr())
+        else:
+            ctxs[k].render_device(frame, bufs[k].data_ptr(), streams[k].cuda_stream)
+    if use_slots:
+        for k in range(F):
+            ctx.wait(k)
     torch.cuda.synchronize(device)
     if world > 1:
         # one untimed reduction of a full-size image: the collective library sets up its channels and buffers at the first
@@ -271,10 +363,12 @@ def main():
     detail = ctx.stats()
     ctx.set_stats_detail(False)
 
-    def timed(cs=None, one_at_a_time=False, repeats=None):
+    def timed(run=None, repeats=None):
         """K steps between barrier + synchronize on both sides, `repeats` times; seconds per repeat (max over ranks)."""
+        run = run or runner
         for _ in range(args.warmup):
-            step(cs, one_at_a_time)
+            run.step()
+        run.drain()
         out_s = []
         reps = repeats or args.repeats
         r = 0
@@ -285,7 +379,8 @@ def main():
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                step(cs, one_at_a_time)
+                run.step()
+            run.drain()
             torch.cuda.synchronize(device)
             if world > 1:
                 dist.barrier()
@@ -305,11 +400,13 @@ def main():
     dt = float(np.median(times))
     dt_min = float(np.min(times))
     mean_img = float(bufs[(step_no[0] - 1) % F][..., :3].mean().item())   # the last (reduced) image
-    # rays of a step: the mean over the last frame of every context (the count moves by a fraction of a percent with `time`)
+    # rays of a step: those of the last frame completed (the count moves by a fraction of a percent with `time`)
     last = [c.stats() for c in ctxs]
     if args.only_timed:
         if rank == 0:
             print(json.dumps({"only_timed": True, "workload": args.workload, "frames_in_flight": F, "steps": args.steps, "repeats": len(times),
+                              "arrangement": "slots of one context" if use_slots else "one context per frame in flight",
+                              "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"),
                               "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_step_min": round(dt_min / args.steps * 1e3, 4),
                               "rays_per_step": int(round(float(np.mean([x["rays"] for x in last]))))}), flush=True)
         for c in ctxs:
@@ -318,8 +415,15 @@ def main():
             dist.destroy_process_group()
         return
     n_rep_other = max(1, min(len(times), 5))
-    # the same K steps, one frame at a time on one context: each frame complete before the next is enqueued
-    times_one = timed([ctxs[0]], one_at_a_time=True, repeats=n_rep_other)
+    # the same K steps, one frame at a time: each frame complete before the next is enqueued
+    if use_slots:
+        times_one = timed(Slots(ctx, 1), repeats=n_rep_other)
+    else:
+        class OneAtATime(Contexts):
+            def step(self):
+                super().step()
+                (comm_stream or streams[0]).synchronize()
+        times_one = timed(OneAtATime([ctxs[0]]), repeats=n_rep_other)
     # ... with a camera that moves a little every frame (the schedule hints then come from a slightly different view)
     make_orbit_views()
     orbit[0] = True
@@ -327,13 +431,43 @@ def main():
     orbit[0] = False
     # ... and with the schedule hints off (what a cut to another view gets: the previous frame's ray counts say nothing)
     os.environ["PT_AMD_NO_COST_HINTS"] = "1"
-    ctxs_nh = [abi.Context(device=local_rank) for _ in range(F)]
+    ctxs_nh = [abi.Context(device=local_rank) for _ in range(len(ctxs))]
     del os.environ["PT_AMD_NO_COST_HINTS"]
     for c in ctxs_nh:
         c.upload_scene(scene)
-    times_nh = timed(ctxs_nh, repeats=n_rep_other)
+    times_nh = timed(Slots(ctxs_nh[0], F) if use_slots else Contexts(ctxs_nh), repeats=n_rep_other)
     for c in ctxs_nh:
         c.close()
+    extra = {}
+    if use_slots:
+        # what the plugin gets through the boundary: binary16 image in page-locked host memory every frame
+        host16 = [ctx.host_array((H, W, 4), np.float16) for _ in range(F)]
+        extra["ms_per_step_plugin_sync"] = round(float(np.median(timed(PluginSync(ctx, host16[0]), repeats=n_rep_other))) / args.steps * 1e3, 4)
+        extra["ms_per_step_plugin_async"] = round(float(np.median(timed(Slots(ctx, F, host=host16, f16=True), repeats=n_rep_other))) / args.steps * 1e3, 4)
+        # the arrangement of earlier records: one context (and one copy of the scene) per frame in flight
+        cs_f = [abi.Context(device=local_rank) for _ in range(F)]
+        for c in cs_f:
+            c.upload_scene(scene)
+        for k in range(F):
+            cs_f[k].render_device(frame, bufs[k].data_ptr(), streams[k].cuda_stream)
+        torch.cuda.synchronize(device)
+        extra["ms_per_step_contexts"] = round(float(np.median(timed(Contexts(cs_f), repeats=n_rep_other))) / args.steps * 1e3, 4)
+        for c in cs_f:
+            c.close()
+        # the headline arrangement in a process that leaves HIP's hardware-queue count alone
+        if not args.default_hw_queues:
+            env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
+                   "--repeats", str(n_rep_other), "--frames-in-flight", str(F), "--only-timed", "--default-hw-queues"]
+            if args.spp:
+                cmd += ["--spp", str(args.spp)]
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                child = json.loads(r.stdout.strip().splitlines()[-1])
+                extra["ms_per_step_default_hw_queues"] = child["ms_per_step"]
+            except Exception as e:   # (reported, not fatal: the headline does not depend on it)
+                extra["ms_per_step_default_hw_queues"] = None
+                extra["default_hw_queues_error"] = repr(e)[:200]
 
     # kernel durations (HIP events recorded by the library on the launch stream), one step at a time
     kernel_ms, paths_ms, primary_ms = [], [], []
@@ -377,11 +511,13 @@ def main():
         achieved_tflops = flops / (k_ms * 1e-3) / 1e12
         traffic = None
         issue = None
+        rocprof_ms = None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
                 prof = json.loads(tf.read_text()).get(args.workload, {})
                 traffic = prof.get("hbm_bytes_per_launch")
+                rocprof_ms = prof.get("k_paths_ms_rocprof")
                 if prof.get("SQ_INSTS_VALU"):
                     # instruction-issue view of the same kernel: VALU wave-instructions per launch by class (rocprofv3 PMC passes
                     # of tools/profile.sh) x the measured issue cost of the class, against the kernel's duration on all SIMDs
@@ -412,6 +548,7 @@ def main():
             "ms_per_step_one_in_flight": round(float(np.median(times_one)) / args.steps * 1e3, 4),
             "ms_per_step_no_hints": round(float(np.median(times_nh)) / args.steps * 1e3, 4),
             "ms_per_step_moving_camera": round(float(np.median(times_mv)) / args.steps * 1e3, 4),
+            **extra,
             "step_definition": "a new frame per step: time advances (new seeds for every pixel, src/raytrace.wgsl:210) and the unchanged object array is "
                                "handed over again (src/extract.rs:297-346)" if not args.fixed_time else "the identical frame every step",
             "higher_is_better": True,
@@ -423,7 +560,10 @@ def main():
                        "bounces": scene.bounces, "objects": int(scene.objects.size), "triangles": scene.n_triangles,
                        "multi_gpu": ("8x8 tiles round-robin over the GPUs + RCCL all-reduce(sum) as gather" if tiles else
                                      "one virtual frame per GPU + RCCL all-reduce(sum) of the f32 radiance buffer") if world > 1 else "single GPU",
-                       "frames_in_flight": F},
+                       "frames_in_flight": F,
+                       "arrangement": "one context, frames on its slots (pt_render_submit_device / pt_render_wait)" if use_slots
+                                      else "one context per frame in flight (pt_render_device on torch streams)",
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default")},
             "rays_per_step": rays_total,
             "rays_definition": "closest-hit queries executed; the primary ray of a pixel is identical for all of its samples "
                                "(src/raytrace.wgsl:223) and is traced once, the reference would trace rays_reference_per_step",
@@ -433,8 +573,14 @@ def main():
             "image_mean": round(mean_img, 6),
             "kernels_ms": {"k_primary": round(float(np.mean(primary_ms)), 4), "k_paths": round(float(np.mean(paths_ms)), 4),
                            "frame": round(float(np.mean(kernel_ms)), 4)},
+            # frac = frac_one_in_flight: the kernel alone on the chip (kernel_ms, HIP events of the library, one frame at a time);
+            # frac_per_step: the same flop over ms_per_step, i.e. with the frames in flight whose kernels overlap (a step is
+            # shorter than one kernel then); kernel_ms_rocprof: the kernel's average in the committed rocprofv3 trace
             "roofline": {"bound": "valu", "kernel": "k_paths", "achieved": round(achieved_tflops, 3), "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VALU_TFLOPS, 5),
+                         "frac_one_in_flight": round(achieved_tflops / PEAK_FP32_VALU_TFLOPS, 5),
+                         "frac_per_step": round(flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS, 5),
+                         "kernel_ms_rocprof": rocprof_ms, "frac_rocprof": round(flops / (rocprof_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS, 5) if rocprof_ms else None,
                          "traffic": traffic,
                          "kernel_ms": round(k_ms, 4), "algorithmic_flop_per_launch": int(flops),
                          "on_chip_bytes_per_launch": int(abytes),
@@ -443,6 +589,10 @@ def main():
                          "valu_issue": issue,
                          "counts": work},
         }
+        if world > 1:
+            # device time of one frame's collective (all-reduce + scale), HIP events on its stream; it runs beside the tracing
+            # of later frames, so it is not a share of ms_per_step
+            line["comm_ms_per_step"] = round(float(np.median(comm_ms)), 4) if comm_ms else None
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_spp, scene.samples))
         print(json.dumps(line), flush=True)

@@ -222,13 +222,13 @@ int pt_render(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_host);
  * the call returns after enqueueing on `hip_stream` (a hipStream_t, or NULL for
  * the context's own stream, in which case the call synchronises before
  * returning). Used by callers that keep the image on the GPU (multi-GPU
- * reduce/gather, on-device post-processing), and by callers that overlap frames:
- * several contexts with the same scene, each on a stream of its own, taking the
- * frames in turn. The library sees on the device whether other frames of the
- * process are running and schedules a frame for throughput then (only as many
- * workgroups as it has work for, fewer of its pixels handed out in small
- * portions) and for latency when it has the device to itself; the image does not
- * depend on the schedule. */
+ * reduce/gather, on-device post-processing). Callers that overlap frames use
+ * pt_render_submit below. The library sees on the device whether other frames of
+ * the process are running (it keeps two scheduling words per device for that,
+ * the only state it has outside its contexts) and schedules a frame for
+ * throughput then (only as many workgroups as it has work for, fewer of its
+ * pixels handed out in small portions) and for latency when it has the device to
+ * itself; the image does not depend on the schedule. */
 int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
                      void* hip_stream);
 
@@ -245,10 +245,49 @@ int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
  * pt_render_device's. The frame leaves no record in the context: pt_get_stats
  * and pt_read_aux do not describe it. All calls on one GPU, from any context,
  * share the array: calls that overlap in time on one GPU race; calls on one
- * stream, or otherwise ordered, are safe. */
+ * stream, or otherwise ordered, are safe. The call records an event behind the
+ * frame; pt_upload_*, pt_get_stats and pt_destroy wait for it, so the scene may be
+ * changed or the context destroyed right after the call. Under stream capture
+ * (hipStreamBeginCapture on `hip_stream`) nothing is recorded or waited for: no
+ * frame of another entry point may be pending on the context when the capture
+ * begins (PT_ERR_NOT_READY otherwise), and the scene must stay as it is for as long
+ * as the captured graph is replayed. */
 #define PT_NOALLOC_MAX_PIXELS 262144u   /* 2^18, e.g. 512 x 512 */
 int pt_render_device_noalloc(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device,
                              void* hip_stream);
+
+/* ---- frames in flight on one context ----------------------------------------- */
+/* The asynchronous form of RayTraceNode::run (reference src/shader.rs:121-213; the
+ * reference records its pass into a command buffer that Bevy's renderer submits
+ * later, which is the same split): pt_render_submit enqueues a frame and returns,
+ * pt_render_wait blocks until that frame's image is complete. A context has
+ * PT_MAX_FRAME_SLOTS slots; each owns a HIP stream and the work memory of one
+ * frame (about 130 bytes per pixel, allocated at the slot's first use), all slots
+ * share the one scene and its acceleration structures. A caller that keeps K
+ * frames in flight uses slots 0..K-1 in turn:
+ *     submit(f0, 0) submit(f1, 1) submit(f2, 2) wait(0) submit(f3, 0) wait(1) ...
+ * so that the start of a frame fills the chip while the previous frame's longest
+ * pixels finish (on the example scenes three frames in flight give 1.3 to 2.8 times
+ * the frame rate of one). Images do not depend on how many frames are in flight.
+ *  - A slot holds one frame: a second submit without a wait in between is refused
+ *    (PT_ERR_INVALID_ARGUMENT).
+ *  - pt_render_submit copies the image to `out_rgba_host` behind the frame (RGBA f32,
+ *    or binary16 with PT_FRAME_OUTPUT_F16); the copy overlaps other frames only when
+ *    that memory is page-locked (pt_host_alloc). pt_render_submit_device leaves it in
+ *    device memory of the context's device (`out_rgba_device`), valid after the wait.
+ *  - pt_upload_objects may be called between submits: frames already submitted keep
+ *    the objects they were submitted with (the library keeps as many versions of the
+ *    instance data and TLAS as frames in flight need); it does not wait for them.
+ *    pt_upload_meshes / pt_upload_materials wait for every frame in flight.
+ *  - PT_FRAME_ACCUMULATE frames are added to the context's accumulation buffer in
+ *    submit order, whatever order they finish in.
+ *  - After pt_render_wait, pt_get_stats / pt_read_aux / pt_debug_wave_log describe
+ *    that slot's frame.
+ * Still one caller thread per context. */
+#define PT_MAX_FRAME_SLOTS 8u
+int pt_render_submit(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* out_rgba_host);
+int pt_render_submit_device(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* out_rgba_device);
+int pt_render_wait(pt_ctx* ctx, uint32_t slot);
 
 /* Page-locked host memory owned by the context, for the image pt_render returns
  * (and for the arrays handed to pt_upload_*): copies to and from it run at the

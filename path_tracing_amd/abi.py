@@ -36,6 +36,7 @@ PT_ACCEL_AUTO, PT_ACCEL_BRUTE, PT_ACCEL_BVH = 0, 1, 2
 PT_TIE_REFERENCE, PT_TIE_LOWEST = 0, 1
 
 PT_NOALLOC_MAX_PIXELS = 1 << 18
+PT_MAX_FRAME_SLOTS = 8
 
 PT_AUX_PRIMARY_OBJECT, PT_AUX_PRIMARY_FLAT_ID, PT_AUX_PRIMARY_T, PT_AUX_RAY_COUNT = 0, 1, 2, 3
 
@@ -112,7 +113,7 @@ assert C.sizeof(PtSettings) == 32 and C.sizeof(PtFrame) == 192 and C.sizeof(PtCo
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_upload_materials",
            "pt_upload_objects", "pt_render", "pt_render_device", "pt_query", "pt_read_aux",
            "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log", "pt_host_alloc", "pt_host_free",
-           "pt_render_device_noalloc",
+           "pt_render_device_noalloc", "pt_render_submit", "pt_render_submit_device", "pt_render_wait",
            "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_upload_meshes", "pt_multi_upload_materials",
            "pt_multi_upload_objects", "pt_multi_render", "pt_multi_context", "pt_multi_rccl_version"]
 
@@ -150,6 +151,9 @@ def load_library():
     lib.pt_render.argtypes = [vp, C.POINTER(PtFrame), vp]
     lib.pt_render_device.argtypes = [vp, C.POINTER(PtFrame), vp, vp]
     lib.pt_render_device_noalloc.argtypes = [vp, C.POINTER(PtFrame), vp, vp]
+    lib.pt_render_submit.argtypes = [vp, C.POINTER(PtFrame), u32, vp]
+    lib.pt_render_submit_device.argtypes = [vp, C.POINTER(PtFrame), u32, vp]
+    lib.pt_render_wait.argtypes = [vp, u32]
     lib.pt_query.argtypes = [vp, vp, u32, vp]
     lib.pt_read_aux.argtypes = [vp, u32, vp, C.c_size_t]
     lib.pt_set_stats_detail.argtypes = [vp, i32]
@@ -366,6 +370,24 @@ class Context:
         """pt_render_device without device-memory allocation (frames of at most PT_NOALLOC_MAX_PIXELS pixels)."""
         self._check(self._lib.pt_render_device_noalloc(self._h, C.byref(frame), C.c_void_p(device_ptr),
                                                        C.c_void_p(stream) if stream else None))
+
+    def submit(self, frame: PtFrame, slot: int, out: np.ndarray):
+        """pt_render_submit: enqueue the frame on `slot`; `out` (a C-contiguous (height, width, 4) array of the frame's output
+        type, best from host_array()) holds the image once wait(slot) has returned. The caller keeps `out` alive until then."""
+        dt = np.float16 if frame.flags & PT_FRAME_OUTPUT_F16 else np.float32
+        if out.dtype != dt or out.shape != (frame.height, frame.width, 4) or not out.flags.c_contiguous:
+            raise ValueError("submit: `out` must be a C-contiguous (height, width, 4) array of the frame's output type")
+        self._check(self._lib.pt_render_submit(self._h, C.byref(frame), slot, _ptr(out)))
+        self.size = (frame.height, frame.width)
+
+    def submit_device(self, frame: PtFrame, slot: int, device_ptr: int):
+        """pt_render_submit_device: the image stays in device memory at `device_ptr`, valid after wait(slot)."""
+        self._check(self._lib.pt_render_submit_device(self._h, C.byref(frame), slot, C.c_void_p(device_ptr)))
+        self.size = (frame.height, frame.width)
+
+    def wait(self, slot: int):
+        """pt_render_wait: blocks until the frame submitted to `slot` is complete; stats()/read_aux() then describe it."""
+        self._check(self._lib.pt_render_wait(self._h, slot))
 
     def query(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)

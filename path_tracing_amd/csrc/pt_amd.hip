@@ -76,90 +76,145 @@ struct FrameKey {
     float wfv[16], vfc[16];
 };
 
-// What the host reads back about a frame once it has finished. Two of them, so that the caller can enqueue frame
+// What the host reads back about a frame once it has finished. Two of them per lane, so that the caller can enqueue frame
 // n+1 while frame n is still running (the launch overhead then hides behind the previous frame's kernels); the
-// device-side work buffers are shared, which stream order makes safe.
+// device-side work buffers of the lane are shared by the two, which stream order makes safe.
 struct FrameSlot {
     hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr;
     DevBuf counters, counters_k1;
     bool pending = false;   // enqueued, not read back yet
     bool detail = false;    // rendered with detailed statistics
+    uint32_t obj_set = 0;   // the object set (instances + TLAS) the frame reads
+    uint32_t accel_used = 0; // PtStats::accel_used of the frame
     uint64_t paths = 0, primary = 0, primary_traced = 0;
+};
+
+constexpr uint32_t kMaxFrameSlots = PT_MAX_FRAME_SLOTS;     // frames one context keeps in flight (pt_render_submit)
+constexpr uint32_t kMaxLanes = 1u + kMaxFrameSlots;
+constexpr uint32_t kMaxObjectSets = kMaxFrameSlots + 2u;     // versions of the instance data + TLAS kept at most
+
+// Everything one frame in flight owns besides the scene: its stream, its work memory (path list, parked pixel state, aux
+// planes, chunk order, image) and the schedule hints its previous frame left. Lane 0 serves the synchronous entry points
+// (pt_render, pt_render_device), lane 1 + k the slot k of pt_render_submit.
+struct Lane {
+    bool ready = false;               // events, counters and stream exist
+    hipStream_t stream = nullptr;     // lane 0: the context's stream; else a stream of its own
+    FrameSlot slot[2];                // host-visible records of the two most recent frames
+    uint64_t frame_seq = 0;           // frames enqueued so far; frame n uses slot[n & 1]
+    hipStream_t last_frame_stream = nullptr;
+    DevBuf d_stack_overflow, d_out, d_out16, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_paths, d_sweeps_done, d_carry, d_cost, d_chunk_bin,
+        d_chunk_order, d_wave_log;
+    uint32_t wave_log_records = 0;
+    uint64_t last_n_paths = ~0ull;    // entries of the path list of the last frame read back
+    uint32_t last_waves_needed = 0;   // its work over its longest chunk, in waves (0: it was not ordered by hints)
+    bool hint_valid = false;          // the aux ray-count plane holds a complete frame described by hint_key
+    FrameKey hint_key;
+    uint32_t aux_w = 0, aux_h = 0;
+    bool submitted = false;           // pt_render_submit without its pt_render_wait yet
+    PtStats stats{};
+    DevBuf* bufs[14] = {&d_stack_overflow, &d_out, &d_out16, &d_aux_obj, &d_aux_flat, &d_aux_t, &d_aux_rays, &d_paths, &d_sweeps_done, &d_carry,
+                        &d_cost, &d_chunk_bin, &d_chunk_order, &d_wave_log};
+    Lane() = default;
+    Lane(const Lane&) = delete;
+    Lane& operator=(const Lane&) = delete;
+};
+
+// One version of what pt_upload_objects derives from the object array: instance records, world boxes and the TLAS the rays
+// walk. A frame reads the version that was current when it was enqueued; an upload writes another one, so that frames in
+// flight are not disturbed (the reference rewrites its object buffer every frame, src/extract.rs:297-346).
+struct ObjectSet {
+    DevBuf w_objects, d_objects, d_obj_l2w, d_obj_lo, d_obj_hi, d_tri_base, d_tlas_nodes;
+    uint32_t n_objects = 0;
+    uint32_t tlas_depth = 0, tlas_root = PT_NONE;   // depth: levels of the 4-wide tree
+    uint32_t tlas_need = 0;                         // traversal stack entries the TLAS walk can need
+    uint32_t tlas_n_wide = 0;                       // nodes of the TLAS
+    uint32_t obj_max_mesh = 0, obj_max_mat = 0;
+    bool use_tlas = false;
+    bool refitted = false;                          // made by a refit of the previous version's tree
+    bool built = false;                             // derived from h_objects and the current meshes
+    DevBuf* bufs[7] = {&w_objects, &d_objects, &d_obj_l2w, &d_obj_lo, &d_obj_hi, &d_tri_base, &d_tlas_nodes};
+    ObjectSet() = default;
+    ObjectSet(const ObjectSet&) = delete;
+    ObjectSet& operator=(const ObjectSet&) = delete;
 };
 
 struct pt_ctx {
     PtConfig cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // uploads, builds, queries, and the frames of the synchronous entry points
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
-    FrameSlot slot[2];            // host-visible records of the two most recent frames
-    uint64_t frame_seq = 0;       // frames enqueued so far; frame n uses slot[n & 1]
-    hipStream_t last_frame_stream = nullptr;
+    Lane lanes[kMaxLanes];
+    uint32_t cur_lane = 0;        // the lane pt_get_stats / pt_read_aux / pt_debug_wave_log describe: that of the last frame completed
+    ObjectSet sets[kMaxObjectSets];
+    uint32_t n_sets = 1;          // versions in use so far
+    uint32_t cur_set = 0;         // the version new frames read
+    // a frame of pt_render_device_noalloc leaves no FrameSlot; this event stands for the last one
+    hipEvent_t ev_noalloc = nullptr;
+    bool noalloc_pending = false;
+    uint32_t noalloc_set = 0;
+    // radiance accumulation is one buffer per context: frames that add to it do so in the order they were enqueued
+    hipEvent_t ev_acc = nullptr;
+    bool acc_pending = false;
+    hipStream_t acc_stream = nullptr;
     std::string err;
     char info[256] = {0};
 
     // uploaded wire arrays (device copies)
-    DevBuf w_meshes, w_indices, w_vertices, w_objects;
+    DevBuf w_meshes, w_indices, w_vertices;
     // traversal layout
     DevBuf d_meshes, d_tris, d_tri_ids, d_attrs, d_tri_lo, d_tri_hi, d_blas_nodes, d_blas_bnodes, d_blas_order;
-    DevBuf d_objects, d_obj_l2w, d_obj_lo, d_obj_hi, d_tlas_nodes, d_tlas_bnodes, d_tri_base;
+    DevBuf d_tlas_bnodes;
     DevBuf d_materials, d_textures, d_texdata;
     // scratch for uploads / builds
     DevBuf t_tri_mesh, t_mesh_first, t_keys0, t_keys1, t_vals0, t_vals1, t_hist, t_par_int, t_par_leaf, t_arrive,
         t_bounds, t_info, t_errors, t_ranges, t_work, t_tris_tmp, t_cstate;
-    // frame outputs
-    DevBuf d_stack_overflow, d_out, d_out16, d_acc, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_rays, d_hits, d_paths, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf, d_sweeps_done, d_carry, d_cost, d_chunk_bin, d_chunk_order, d_wave_log;
+    // the topology of the TLAS a refit keeps (upload stream only), query buffers, accumulation
+    DevBuf d_acc, d_rays, d_hits, d_tlas_order, d_tlas_par_int, d_tlas_par_leaf;
 
     std::vector<DMesh> h_meshes;
     std::vector<uint32_t> h_blas_nodes_base;  // per mesh: first node of its BLAS (or PT_NONE)
     std::vector<uint32_t> h_blas_n_wide;      // per mesh: nodes of its (4-wide) BLAS
-    uint32_t n_meshes = 0, n_tris = 0, n_objects = 0, n_materials = 0, n_textures = 0, n_texdata = 0;
+    uint32_t n_meshes = 0, n_tris = 0, n_materials = 0, n_textures = 0, n_texdata = 0;
     uint32_t n_blas_nodes = 0;
-    uint32_t obj_max_mesh = 0, obj_max_mat = 0;
-    uint32_t max_blas_depth = 0, tlas_depth = 0, tlas_root = PT_NONE;   // depths: levels of the 4-wide trees
-    uint32_t max_blas_need = 0, tlas_need = 0;   // traversal stack entries a BLAS / the TLAS walk can need
-    uint32_t tlas_n_wide = 0;                    // nodes of the TLAS
+    uint32_t max_blas_depth = 0;   // levels of the deepest 4-wide BLAS
+    uint32_t max_blas_need = 0;    // traversal stack entries a BLAS walk can need
     uint32_t tlas_top_max = PT_NONE;             // nodes of its top levels k_paths stages in LDS at most (PT_NONE: what fits beside four workgroups per compute unit)
     uint32_t lds_stack_max = 16;                 // PT_MODE_TLAS, k_paths: traversal stack entries per lane kept in LDS
     bool have_meshes = false, have_materials = false, have_objects = false;
-    bool objects_built = false;   // the instance data on the device was derived from h_objects and the current meshes
-    bool use_tlas = false;
     std::vector<PtObject> h_objects;  // kept so that a mesh re-upload can rebuild the instance data
 
     unsigned char* scratch = nullptr;   // this device's no-allocation work array (pt_render_device_noalloc), or null
     uint32_t n_cus = 256;
     uint32_t chunk_pixels = 64;   // see PathParams::chunk
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
-    uint32_t wave_log_records = 0;
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
     std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
     bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
-    uint64_t last_n_paths = ~0ull; // entries of the path list of the last frame read back
-    uint32_t last_waves_needed = 0; // its work over its longest chunk, in waves (0: it was not ordered by hints)
     int list_regs = 0;             // object-list variants of k_paths: 0 chosen per frame, 1 always the build for four waves per SIMD, 2 always the roomy one
     uint32_t walk_quota = 16;     // see PathParams::walk_quota
     uint32_t blas_max_leaf = 2;   // triangles a BLAS leaf holds at most (1..PT_WIDE_MAX_LEAF); 2 measured best on the 968-triangle mesh of scene.glb
     bool carry_acquire = true;    // see PathParams::carry_acquire (costs about 1 % of a frame; PT_AMD_CARRY_ACQUIRE=0 leaves it out)
     bool split_chunks = true;     // see PathParams::split_chunks: the most expensive chunks of list-mode scenes in four parts (shorter single frames, and more frames per second since the workgroups of such scenes leave wave slots free)
     bool lds_blas = true;         // object-list scenes: stage the biggest BLAS that fits in LDS (k_paths)
+    bool lds_blas_nodes_only = false;   // ... its nodes only, never the triangle records (PT_AMD_LDS_BLAS_NODES_ONLY)
+    bool lds_scene = true;        // small scenes are staged in LDS whole (PT_AMD_NO_LDS_SCENE switches it off)
+    bool k1_narrow = false;       // k_primary with four waves per workgroup even where sixteen fit (PT_AMD_K1_NARROW)
+    int blocks_per_cu = 0;        // workgroups of k_paths per compute unit at most (PT_AMD_BLOCKS_PER_CU; 0: what fits)
+    bool debug = false;           // PT_AMD_DEBUG: a line per frame on stderr
     uint32_t lds_per_cu = 160 * 1024;
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
     uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
     uint32_t tlas_refits = 0;     // refits since that build
-    bool tlas_refitted = false;   // the last object upload refitted
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
     uint32_t split_fraction[2] = {PT_SPLIT_FRACTION_ALONE, PT_SPLIT_FRACTION};   // at most 1/this of the chunks are handed out in parts {frame alone on the device, other frames running}
     uint32_t split_load_8ths = 16;                 // chunks are handed out in parts only while work / longest chunk <= this/8 x the waves of the launch; 0: always
     uint32_t group_margin_8ths[2] = {24, 8};       // see ChunkOrderInfo::n_groups: waves = this/8 x work / longest chunk, {frame alone on the device, other frames running}; 0: always the whole grid
     bool blas_sah = true;         // BLAS of moderate meshes by the surface-area heuristic on the host (else Morton order)
     bool strict_hints = false;    // see render_enqueue
-    bool hint_valid = false;      // the aux ray-count plane holds a complete frame described by hint_key
-    FrameKey hint_key;
     uint64_t scene_version = 0;   // bumped by every upload
-    uint32_t aux_w = 0, aux_h = 0;
     uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
     bool stats_detail = false;
-    PtStats stats{};
+    double build_ms = 0.0;        // device time of the last TLAS build or refit
 };
 
 namespace {
@@ -390,8 +445,10 @@ int collapse_wide(pt_ctx* ctx, const BvhNode* bnodes, uint32_t bnode_base, uint3
     return PT_OK;
 }
 
-int rebuild_objects(pt_ctx* ctx);
-int finish_timing(pt_ctx* ctx);
+int rebuild_objects(pt_ctx* ctx, uint32_t target);
+int acquire_object_set(pt_ctx* ctx, uint32_t* target);
+int finish_all(pt_ctx* ctx);
+hipError_t lane_init(pt_ctx* ctx, Lane& L, bool own_stream);
 
 }  // namespace
 
@@ -443,6 +500,11 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (const char* e = std::getenv("PT_AMD_LDS_STACK")) { int v = std::atoi(e); if (v >= 4 && v <= (int)kMaxStackDepth) ctx->lds_stack_max = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_TLAS_TOP")) { int v = std::atoi(e); if (v >= 0 && v <= 2048) ctx->tlas_top_max = (uint32_t)v; }
         if (std::getenv("PT_AMD_NO_LDS_BLAS")) ctx->lds_blas = false;
+        if (std::getenv("PT_AMD_LDS_BLAS_NODES_ONLY")) ctx->lds_blas_nodes_only = true;
+        if (std::getenv("PT_AMD_NO_LDS_SCENE")) ctx->lds_scene = false;
+        if (std::getenv("PT_AMD_K1_NARROW")) ctx->k1_narrow = true;
+        if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->blocks_per_cu = v; }
+        if (std::getenv("PT_AMD_DEBUG")) ctx->debug = true;
         if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
         if (std::getenv("PT_AMD_NO_QUEUE_AHEAD")) ctx->queue_ahead = false;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
@@ -451,15 +513,11 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
                       prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1073741824.0);
         hipError_t e = hipSetDevice(ctx->device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        for (FrameSlot& sl : ctx->slot) {
-            if (e == hipSuccess) e = hipEventCreate(&sl.ev0);
-            if (e == hipSuccess) e = hipEventCreate(&sl.ev1);
-            if (e == hipSuccess) e = hipEventCreate(&sl.evm);
-            if (e == hipSuccess) e = sl.counters.ensure(sizeof(DCounters));
-            if (e == hipSuccess) e = sl.counters_k1.ensure(sizeof(DCounters));
-        }
+        if (e == hipSuccess) e = lane_init(ctx, ctx->lanes[0], false);
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb0);
         if (e == hipSuccess) e = hipEventCreate(&ctx->evb1);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_noalloc, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming);
         if (e == hipSuccess && ctx->device < kMaxDevices) {
             // this device's copy of the no-allocation work array (the device is current here)
             std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -487,29 +545,40 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
 int pt_destroy(pt_ctx* ctx) {
     if (!ctx) return PT_OK;
     (void)hipSetDevice(ctx->device);
-    // frames may still be running on a caller's stream: wait for them before any buffer they use is released
-    for (FrameSlot& sl : ctx->slot)
-        if (sl.ev1 && sl.pending) (void)hipEventSynchronize(sl.ev1);
+    // frames may still be running on a caller's stream or on the lanes' own: wait for them before any buffer they use is released
+    for (Lane& L : ctx->lanes) {
+        for (FrameSlot& sl : L.slot)
+            if (sl.ev1 && sl.pending) (void)hipEventSynchronize(sl.ev1);
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+    }
+    if (ctx->ev_noalloc && ctx->noalloc_pending) (void)hipEventSynchronize(ctx->ev_noalloc);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->w_meshes, &ctx->w_indices, &ctx->w_vertices, &ctx->w_objects, &ctx->d_meshes, &ctx->d_tris,
-                      &ctx->d_attrs, &ctx->d_tri_lo, &ctx->d_tri_hi, &ctx->d_blas_nodes, &ctx->d_objects, &ctx->d_obj_lo,
-                      &ctx->d_obj_hi, &ctx->d_tlas_nodes, &ctx->d_tri_base, &ctx->d_materials, &ctx->d_textures,
+    DevBuf* bufs[] = {&ctx->w_meshes, &ctx->w_indices, &ctx->w_vertices, &ctx->d_meshes, &ctx->d_tris,
+                      &ctx->d_attrs, &ctx->d_tri_lo, &ctx->d_tri_hi, &ctx->d_blas_nodes, &ctx->d_materials, &ctx->d_textures,
                       &ctx->d_texdata, &ctx->t_tri_mesh, &ctx->t_mesh_first, &ctx->t_keys0, &ctx->t_keys1, &ctx->t_vals0,
                       &ctx->t_vals1, &ctx->t_hist, &ctx->t_par_int, &ctx->t_par_leaf, &ctx->t_arrive, &ctx->t_bounds,
-                      &ctx->t_info, &ctx->t_errors, &ctx->d_out, &ctx->d_out16, &ctx->d_acc, &ctx->d_aux_obj, &ctx->d_aux_flat,
-                      &ctx->d_aux_t, &ctx->d_aux_rays, &ctx->d_rays, &ctx->d_hits, &ctx->d_paths, &ctx->d_tlas_order, &ctx->d_tlas_par_int, &ctx->d_tlas_par_leaf, &ctx->d_sweeps_done, &ctx->d_carry, &ctx->d_cost, &ctx->d_chunk_bin, &ctx->d_chunk_order, &ctx->d_wave_log,
-                      &ctx->d_stack_overflow, &ctx->d_tri_ids, &ctx->d_blas_bnodes, &ctx->d_blas_order, &ctx->d_obj_l2w, &ctx->d_tlas_bnodes, &ctx->t_ranges, &ctx->t_work, &ctx->t_tris_tmp, &ctx->t_cstate};
+                      &ctx->t_info, &ctx->t_errors, &ctx->d_acc, &ctx->d_rays, &ctx->d_hits, &ctx->d_tlas_order, &ctx->d_tlas_par_int,
+                      &ctx->d_tlas_par_leaf, &ctx->d_tri_ids, &ctx->d_blas_bnodes, &ctx->d_blas_order, &ctx->d_tlas_bnodes, &ctx->t_ranges,
+                      &ctx->t_work, &ctx->t_tris_tmp, &ctx->t_cstate};
     for (DevBuf* b : bufs) b->release();
+    for (ObjectSet& os : ctx->sets)
+        for (DevBuf* b : os.bufs) b->release();
     for (void* p : ctx->host_allocs) (void)hipHostFree(p);
-    for (FrameSlot& sl : ctx->slot) {
-        sl.counters.release();
-        sl.counters_k1.release();
-        if (sl.ev0) (void)hipEventDestroy(sl.ev0);
-        if (sl.ev1) (void)hipEventDestroy(sl.ev1);
-        if (sl.evm) (void)hipEventDestroy(sl.evm);
+    for (Lane& L : ctx->lanes) {
+        for (DevBuf* b : L.bufs) b->release();
+        for (FrameSlot& sl : L.slot) {
+            sl.counters.release();
+            sl.counters_k1.release();
+            if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+            if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+            if (sl.evm) (void)hipEventDestroy(sl.evm);
+        }
+        if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
     }
     if (ctx->evb0) (void)hipEventDestroy(ctx->evb0);
     if (ctx->evb1) (void)hipEventDestroy(ctx->evb1);
+    if (ctx->ev_noalloc) (void)hipEventDestroy(ctx->ev_noalloc);
+    if (ctx->ev_acc) (void)hipEventDestroy(ctx->ev_acc);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PT_OK;
@@ -526,7 +595,7 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
                      const PtVertex* vertices, uint32_t n_vertices) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
-        { int rc_wait = finish_timing(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
+        { int rc_wait = finish_all(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
         if ((n_meshes && !meshes) || (n_indices && !indices) || (n_vertices && !vertices))
             return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_meshes: null array with non-zero count");
         PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -580,6 +649,9 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
             for (uint32_t i = 0; i < me.tri_count; ++i) tri_mesh[acc + i] = m;
             bool want_blas = (ctx->cfg.accel == PT_ACCEL_BVH && me.tri_count >= 2) ||
                              (ctx->cfg.accel == PT_ACCEL_AUTO && me.tri_count > kBlasMinTris);
+            // (a BLAS leaf names its first triangle by its position in the mesh in PT_WLEAF_COUNT_SHIFT bits)
+            if (want_blas && me.tri_count > PT_WLEAF_POS_MASK + 1u)
+                return fail(ctx, PT_ERR_UNSUPPORTED, "pt_upload_meshes: mesh " + std::to_string(m) + " has more than 2^29 triangles");
             if (want_blas) {
                 node_base[m] = n_nodes;
                 n_nodes += me.tri_count - 1;
@@ -663,8 +735,10 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
         ctx->have_meshes = true;
         ctx->scene_version++;
         ctx->acc_frames = 0;
-        // instance data depends on the mesh table (world boxes, flat triangle ids)
-        if (ctx->have_objects) return rebuild_objects(ctx);
+        // instance data depends on the mesh table (world boxes, flat triangle ids); no frame is in flight, so the current
+        // version is rebuilt where it is, without the tree of the old meshes
+        ctx->tlas_built_n = 0;
+        if (ctx->have_objects) return rebuild_objects(ctx, ctx->cur_set);
         return PT_OK;
     } catch (const std::bad_alloc&) {
         return fail(ctx, PT_ERR_OUT_OF_MEMORY, "pt_upload_meshes: host allocation failed");
@@ -678,7 +752,7 @@ int pt_upload_materials(pt_ctx* ctx, const PtMaterial* materials, uint32_t n_mat
                         uint32_t n_textures, const float* texture_data, uint32_t n_texture_data) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
-        { int rc_wait = finish_timing(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
+        { int rc_wait = finish_all(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
         if ((n_materials && !materials) || (n_textures && !textures) || (n_texture_data && !texture_data))
             return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_upload_materials: null array with non-zero count");
         for (uint32_t m = 0; m < n_materials; ++m) {
@@ -723,20 +797,25 @@ int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects) 
         }
         // The reference rewrites the object buffer every frame (src/extract.rs:297-346), mostly with the same bytes:
         // then the instance data, the TLAS, the cost hints and the frames in flight all stay as they are.
-        if (ctx->have_objects && ctx->objects_built && ctx->h_objects.size() == n_objects &&
+        if (ctx->have_objects && ctx->sets[ctx->cur_set].built && ctx->h_objects.size() == n_objects &&
             (n_objects == 0 || std::memcmp(ctx->h_objects.data(), objects, sizeof(PtObject) * (size_t)n_objects) == 0))
             return PT_OK;
-        { int rc_wait = finish_timing(ctx); if (rc_wait != PT_OK) return rc_wait; }   // no frame may still be reading the scene
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        // The new version goes into a set of buffers that no frame in flight reads (frames keep the version they were
+        // enqueued with), so an upload per frame does not drain the frames in flight.
+        uint32_t target = ctx->cur_set;
+        { int rc_set = acquire_object_set(ctx, &target); if (rc_set != PT_OK) return rc_set; }
         ctx->h_objects.assign(objects, objects + n_objects);
         ctx->have_objects = true;
-        ctx->objects_built = false;
         ctx->scene_version++;
         ctx->acc_frames = 0;
         if (!ctx->have_meshes) {  // instance data is derived once the mesh table exists
-            ctx->n_objects = n_objects;
+            ctx->sets[target].built = false;
+            ctx->sets[target].n_objects = n_objects;
+            ctx->cur_set = target;
             return PT_OK;
         }
-        return rebuild_objects(ctx);
+        return rebuild_objects(ctx, target);
     } catch (const std::bad_alloc&) {
         return fail(ctx, PT_ERR_OUT_OF_MEMORY, "pt_upload_objects: host allocation failed");
     } catch (...) {
@@ -748,18 +827,67 @@ int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects) 
 
 namespace {
 
-int rebuild_objects(pt_ctx* ctx) {
+// Events, counters and (for the lanes of pt_render_submit) a stream of its own.
+hipError_t lane_init(pt_ctx* ctx, Lane& L, bool own_stream) {
+    if (L.ready) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (own_stream) e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+    else L.stream = ctx->stream;
+    for (FrameSlot& sl : L.slot) {
+        if (e == hipSuccess && !sl.ev0) e = hipEventCreate(&sl.ev0);
+        if (e == hipSuccess && !sl.ev1) e = hipEventCreate(&sl.ev1);
+        if (e == hipSuccess && !sl.evm) e = hipEventCreate(&sl.evm);
+        if (e == hipSuccess) e = sl.counters.ensure(sizeof(DCounters));
+        if (e == hipSuccess) e = sl.counters_k1.ensure(sizeof(DCounters));
+    }
+    L.ready = e == hipSuccess;
+    return e;
+}
+
+// Does a frame that has been enqueued and may still be running read object set k?
+bool object_set_busy(pt_ctx* ctx, uint32_t k) {
+    for (Lane& L : ctx->lanes)
+        for (FrameSlot& sl : L.slot)
+            if (sl.pending && sl.obj_set == k && hipEventQuery(sl.ev1) != hipSuccess) return true;
+    if (ctx->noalloc_pending && ctx->noalloc_set == k && hipEventQuery(ctx->ev_noalloc) != hipSuccess) return true;
+    return false;
+}
+
+int finish_slot(pt_ctx* ctx, Lane& L, FrameSlot& sl);
+
+// The set of buffers the next version of the instance data goes into: the current one when no frame in flight reads it
+// (callers that render one frame at a time keep a single version), else one that is free, else a new one, else -- every
+// version in use -- the one after the current, once its frames have finished.
+int acquire_object_set(pt_ctx* ctx, uint32_t* target) {
+    if (!object_set_busy(ctx, ctx->cur_set)) { *target = ctx->cur_set; return PT_OK; }
+    for (uint32_t k = 0; k < ctx->n_sets; ++k)
+        if (k != ctx->cur_set && !object_set_busy(ctx, k)) { *target = k; return PT_OK; }
+    if (ctx->n_sets < kMaxObjectSets) { *target = ctx->n_sets++; return PT_OK; }
+    const uint32_t k = (ctx->cur_set + 1u) % ctx->n_sets;
+    for (Lane& L : ctx->lanes)
+        for (FrameSlot& sl : L.slot)
+            if (sl.pending && sl.obj_set == k) { int rc = finish_slot(ctx, L, sl); if (rc != PT_OK) return rc; }
+    if (ctx->noalloc_pending && ctx->noalloc_set == k) { PT_HIP(ctx, hipEventSynchronize(ctx->ev_noalloc)); ctx->noalloc_pending = false; }
+    *target = k;
+    return PT_OK;
+}
+
+// Derives version `target` of the instance data (records, world boxes, TLAS) from h_objects and the current meshes, on the
+// context's stream, and makes it the current one. Frames in flight keep reading the versions they were enqueued with; the
+// caller has made sure that none of them reads `target`.
+int rebuild_objects(pt_ctx* ctx, uint32_t target) {
     const uint32_t n = (uint32_t)ctx->h_objects.size();
     PT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     PT_HIP(ctx, hipStreamSynchronize(s));
+    ObjectSet& T = ctx->sets[target];
+    const ObjectSet& P = ctx->sets[ctx->cur_set];   // the version before (may be the same buffers)
     std::vector<uint32_t> tri_base(n);
     uint64_t acc = 0;
     uint32_t max_mesh = 0, max_mat = 0;
     for (uint32_t o = 0; o < n; ++o) {
         const PtObject& ob = ctx->h_objects[o];
         if (ob.mesh >= ctx->n_meshes) {
-            ctx->n_objects = 0;
             ctx->have_objects = false;
             return fail(ctx, PT_ERR_INVALID_SCENE, "pt_upload_objects: object " + std::to_string(o) + " references a mesh past meshes[]");
         }
@@ -769,36 +897,39 @@ int rebuild_objects(pt_ctx* ctx) {
         max_mat = std::max(max_mat, ob.mat);
     }
     if (acc >= 0xFFFFFFFFull) {
-        ctx->n_objects = 0;
         ctx->have_objects = false;
         return fail(ctx, PT_ERR_UNSUPPORTED, "pt_upload_objects: more than 2^32-1 instanced triangles");
     }
-    ctx->obj_max_mesh = max_mesh;
-    ctx->obj_max_mat = max_mat;
-    ctx->n_objects = n;
-    const uint32_t kept[4] = {ctx->tlas_n_wide, ctx->tlas_depth, ctx->tlas_root, ctx->tlas_need};   // of the tree a refit keeps
-    ctx->tlas_root = PT_NONE;
-    ctx->tlas_depth = 0;
-    ctx->tlas_need = 0;
-    ctx->tlas_n_wide = 0;
-    ctx->use_tlas = false;
-    ctx->stats.build_ms = 0.0;
-    ctx->objects_built = false;
-    if (n == 0) { ctx->objects_built = true; return PT_OK; }
+    // of the tree a refit keeps
+    const bool have_kept = P.built && P.use_tlas && P.tlas_n_wide > 0;
+    const uint32_t kept[4] = {have_kept ? P.tlas_n_wide : 0u, P.tlas_depth, P.tlas_root, P.tlas_need};
+    const WNode* kept_nodes = P.d_tlas_nodes.as<WNode>();
+    T.obj_max_mesh = max_mesh;
+    T.obj_max_mat = max_mat;
+    T.n_objects = n;
+    T.tlas_root = PT_NONE;
+    T.tlas_depth = 0;
+    T.tlas_need = 0;
+    T.tlas_n_wide = 0;
+    T.use_tlas = false;
+    T.refitted = false;
+    T.built = false;
+    ctx->build_ms = 0.0;
+    if (n == 0) { T.built = true; ctx->cur_set = target; return PT_OK; }
 
-    PT_HIP(ctx, ctx->w_objects.ensure(sizeof(PtObject) * (size_t)n));
-    PT_HIP(ctx, ctx->d_objects.ensure(sizeof(DObject) * (size_t)n));
-    PT_HIP(ctx, ctx->d_obj_l2w.ensure(sizeof(Affine) * (size_t)n));
-    PT_HIP(ctx, ctx->d_obj_lo.ensure(sizeof(float4) * (size_t)n));
-    PT_HIP(ctx, ctx->d_obj_hi.ensure(sizeof(float4) * (size_t)n));
-    PT_HIP(ctx, ctx->d_tri_base.ensure(sizeof(uint32_t) * (size_t)n));
+    PT_HIP(ctx, T.w_objects.ensure(sizeof(PtObject) * (size_t)n));
+    PT_HIP(ctx, T.d_objects.ensure(sizeof(DObject) * (size_t)n));
+    PT_HIP(ctx, T.d_obj_l2w.ensure(sizeof(Affine) * (size_t)n));
+    PT_HIP(ctx, T.d_obj_lo.ensure(sizeof(float4) * (size_t)n));
+    PT_HIP(ctx, T.d_obj_hi.ensure(sizeof(float4) * (size_t)n));
+    PT_HIP(ctx, T.d_tri_base.ensure(sizeof(uint32_t) * (size_t)n));
     PT_HIP(ctx, ctx->t_info.ensure(sizeof(uint32_t) * 8 * (size_t)(ctx->n_meshes + 1)));
-    PT_HIP(ctx, hipMemcpyAsync(ctx->w_objects.p, ctx->h_objects.data(), sizeof(PtObject) * (size_t)n, hipMemcpyHostToDevice, s));
-    PT_HIP(ctx, hipMemcpyAsync(ctx->d_tri_base.p, tri_base.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    PT_HIP(ctx, hipMemcpyAsync(T.w_objects.p, ctx->h_objects.data(), sizeof(PtObject) * (size_t)n, hipMemcpyHostToDevice, s));
+    PT_HIP(ctx, hipMemcpyAsync(T.d_tri_base.p, tri_base.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     PT_HIP(ctx, hipEventRecord(ctx->evb0, s));
-    k_prep_objects<<<div_up(n, 256), 256, 0, s>>>(ctx->w_objects.as<WObject>(), ctx->d_tri_base.as<uint32_t>(),
-                                                  ctx->d_meshes.as<DMesh>(), n, ctx->d_objects.as<DObject>(), ctx->d_obj_l2w.as<Affine>(),
-                                                  ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>());
+    k_prep_objects<<<div_up(n, 256), 256, 0, s>>>(T.w_objects.as<WObject>(), T.d_tri_base.as<uint32_t>(),
+                                                  ctx->d_meshes.as<DMesh>(), n, T.d_objects.as<DObject>(), T.d_obj_l2w.as<Affine>(),
+                                                  T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>());
     PT_HIP(ctx, hipGetLastError());
     const bool want_tlas = (ctx->cfg.accel == PT_ACCEL_BVH) || (ctx->cfg.accel == PT_ACCEL_AUTO && n > kTlasMinObjects);
     uint32_t cinfo[4] = {0, 0, PT_NONE, 0};   // collapse info: nodes, levels, root, stack need
@@ -811,27 +942,30 @@ int rebuild_objects(pt_ctx* ctx) {
             uint32_t* slot = ctx->t_info.as<uint32_t>() + 8 * (size_t)ctx->n_meshes;
             PT_HIP(ctx, hipMemsetAsync(slot, 0, 8 * sizeof(uint32_t), s));
             const size_t nb = sizeof(uint32_t) * (size_t)n;
+            PT_HIP(ctx, T.d_tlas_nodes.ensure(sizeof(WNode) * (size_t)(n - 1)));
             // Same number of objects as the tree was built for: keep the binary tree's topology (leaf order and parent
             // links) and only fit the boxes again, bottom-up. Any valid tree gives the same image; a stale topology only
             // costs traversal steps, so a fresh build is made every kTlasMaxRefits updates. The 4-wide tree keeps its
-            // topology too: its nodes take the new boxes from the binary nodes they were made from.
+            // topology too: its nodes (copied from the version before when this one has buffers of its own) take the new
+            // boxes from the binary nodes they were made from.
             if (ctx->allow_refit && ctx->tlas_built_n == n && ctx->tlas_refits < kTlasMaxRefits && kept[0] > 0) {
                 PT_HIP(ctx, ctx->t_arrive.ensure(nb));
                 PT_HIP(ctx, hipMemsetAsync(ctx->t_arrive.p, 0, nb, s));
-                k_fit<<<div_up(n, 256), 256, 0, s>>>(ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, ctx->d_tlas_order.as<uint32_t>(), n,
+                k_fit<<<div_up(n, 256), 256, 0, s>>>(T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, ctx->d_tlas_order.as<uint32_t>(), n,
                                                      ctx->d_tlas_par_int.as<uint32_t>(), ctx->d_tlas_par_leaf.as<uint32_t>(),
                                                      ctx->t_arrive.as<uint32_t>(), ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, 0u);
                 PT_HIP(ctx, hipGetLastError());
-                k_requantise<<<div_up(kept[0], 256), 256, 0, s>>>(ctx->d_tlas_nodes.as<WNode>(), 0, kept[0], ctx->d_tlas_bnodes.as<BvhNode>(),
-                                                                  ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>());
+                if (kept_nodes != T.d_tlas_nodes.as<WNode>())
+                    PT_HIP(ctx, hipMemcpyAsync(T.d_tlas_nodes.p, kept_nodes, sizeof(WNode) * (size_t)kept[0], hipMemcpyDeviceToDevice, s));
+                k_requantise<<<div_up(kept[0], 256), 256, 0, s>>>(T.d_tlas_nodes.as<WNode>(), 0, kept[0], ctx->d_tlas_bnodes.as<BvhNode>(),
+                                                                  T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>());
                 PT_HIP(ctx, hipGetLastError());
                 std::memcpy(cinfo, kept, sizeof cinfo);
                 ctx->tlas_refits++;
                 refitted = true;
             } else {
                 PT_HIP(ctx, ctx->d_tlas_bnodes.ensure(sizeof(BvhNode) * (size_t)(n - 1)));
-                PT_HIP(ctx, ctx->d_tlas_nodes.ensure(sizeof(WNode) * (size_t)(n - 1)));
-                int rc = build_lbvh(ctx, ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false);
+                int rc = build_lbvh(ctx, T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false);
                 if (rc != PT_OK) return rc;
                 PT_HIP(ctx, ctx->d_tlas_order.ensure(nb));
                 PT_HIP(ctx, ctx->d_tlas_par_int.ensure(nb));
@@ -841,23 +975,24 @@ int rebuild_objects(pt_ctx* ctx) {
                 PT_HIP(ctx, hipMemcpyAsync(ctx->d_tlas_par_leaf.p, ctx->t_par_leaf.p, nb, hipMemcpyDeviceToDevice, s));
                 ctx->tlas_built_n = n;
                 ctx->tlas_refits = 0;
-                rc = collapse_wide(ctx, ctx->d_tlas_bnodes.as<BvhNode>(), 0, n, false, ctx->d_tlas_nodes.as<WNode>(), 0, slot + 4, slot);
+                rc = collapse_wide(ctx, ctx->d_tlas_bnodes.as<BvhNode>(), 0, n, false, T.d_tlas_nodes.as<WNode>(), 0, slot + 4, slot);
                 if (rc != PT_OK) return rc;
                 PT_HIP(ctx, hipMemcpyAsync(cinfo, slot + 4, sizeof cinfo, hipMemcpyDeviceToHost, s));
             }
         }
-        ctx->use_tlas = true;
+        T.use_tlas = true;
     }
     PT_HIP(ctx, hipEventRecord(ctx->evb1, s));
     PT_HIP(ctx, hipStreamSynchronize(s));
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ctx->evb0, ctx->evb1) == hipSuccess) ctx->stats.build_ms = ms;
-    ctx->tlas_n_wide = cinfo[0];
-    ctx->tlas_depth = cinfo[1];
-    ctx->tlas_root = want_tlas ? cinfo[2] : PT_NONE;
-    ctx->tlas_need = cinfo[3];
-    ctx->tlas_refitted = refitted;
-    ctx->objects_built = true;
+    if (hipEventElapsedTime(&ms, ctx->evb0, ctx->evb1) == hipSuccess) ctx->build_ms = ms;
+    T.tlas_n_wide = cinfo[0];
+    T.tlas_depth = cinfo[1];
+    T.tlas_root = want_tlas ? cinfo[2] : PT_NONE;
+    T.tlas_need = cinfo[3];
+    T.refitted = refitted;
+    T.built = true;
+    ctx->cur_set = target;
     return PT_OK;
 }
 
@@ -865,17 +1000,19 @@ int rebuild_objects(pt_ctx* ctx) {
 // counted exactly when the tree is made) plus what the walk of the deepest BLAS adds on top of it, plus the three words
 // of headroom wide_visit() writes into. (LDS per workgroup decides how many workgroups fit on a compute unit.)
 uint32_t stack_depth_needed(const pt_ctx* ctx) {
+    const ObjectSet& os = ctx->sets[ctx->cur_set];
     uint32_t d = ctx->max_blas_need;
-    if (ctx->use_tlas) d += ctx->tlas_need;
+    if (os.use_tlas) d += os.tlas_need;
     return d + 3u;
 }
 
 int check_ready(pt_ctx* ctx, const char* who) {
-    if (!ctx->have_meshes || !ctx->have_materials || !ctx->have_objects)
+    const ObjectSet& os = ctx->sets[ctx->cur_set];
+    if (!ctx->have_meshes || !ctx->have_materials || !ctx->have_objects || !os.built)
         return fail(ctx, PT_ERR_NOT_READY, std::string(who) + ": meshes, materials and objects must all have been uploaded");
-    if (ctx->n_objects) {
-        if (ctx->obj_max_mesh >= ctx->n_meshes) return fail(ctx, PT_ERR_INVALID_SCENE, std::string(who) + ": an object references a mesh past meshes[]");
-        if (ctx->obj_max_mat >= ctx->n_materials) return fail(ctx, PT_ERR_INVALID_SCENE, std::string(who) + ": an object references a material past materials[]");
+    if (os.n_objects) {
+        if (os.obj_max_mesh >= ctx->n_meshes) return fail(ctx, PT_ERR_INVALID_SCENE, std::string(who) + ": an object references a mesh past meshes[]");
+        if (os.obj_max_mat >= ctx->n_materials) return fail(ctx, PT_ERR_INVALID_SCENE, std::string(who) + ": an object references a material past materials[]");
     }
     if (stack_depth_needed(ctx) > kMaxStackDepth)
         return fail(ctx, PT_ERR_UNSUPPORTED, std::string(who) + ": acceleration structure deeper than the traversal stack; create the context with PT_ACCEL_BRUTE");
@@ -883,23 +1020,24 @@ int check_ready(pt_ctx* ctx, const char* who) {
 }
 
 SceneView make_view(const pt_ctx* ctx) {
+    const ObjectSet& os = ctx->sets[ctx->cur_set];
     SceneView v;
-    v.objects = ctx->d_objects.as<DObject>();
-    v.obj_l2w = ctx->d_obj_l2w.as<Affine>();
+    v.objects = os.d_objects.as<DObject>();
+    v.obj_l2w = os.d_obj_l2w.as<Affine>();
     v.meshes = ctx->d_meshes.as<DMesh>();
     v.tris = ctx->d_tris.as<DTri>();
     v.tri_ids = ctx->d_tri_ids.as<uint32_t>();
     v.tri_attrs = ctx->d_attrs.as<DTriAttr>();
     v.blas_nodes = ctx->d_blas_nodes.as<WNode>();
-    v.tlas_nodes = ctx->d_tlas_nodes.as<WNode>();
-    v.obj_lo = ctx->d_obj_lo.as<float4>();
-    v.obj_hi = ctx->d_obj_hi.as<float4>();
+    v.tlas_nodes = os.d_tlas_nodes.as<WNode>();
+    v.obj_lo = os.d_obj_lo.as<float4>();
+    v.obj_hi = os.d_obj_hi.as<float4>();
     v.materials = ctx->d_materials.as<DMaterial>();
     v.textures = ctx->d_textures.as<DTexture>();
     v.texture_data = ctx->d_texdata.as<float>();
-    v.n_objects = ctx->n_objects;
+    v.n_objects = os.n_objects;
     v.n_texture_data = ctx->n_texdata;
-    v.tlas_root = ctx->tlas_root;
+    v.tlas_root = os.tlas_root;
     v.tie_lowest = (ctx->cfg.tie_rule == PT_TIE_LOWEST) ? 1u : 0u;
     v.cull_boxes = (ctx->cfg.accel == PT_ACCEL_BRUTE) ? 0u : 1u;
     v._pad0 = 0;
@@ -911,8 +1049,8 @@ SceneView make_view(const pt_ctx* ctx) {
     return v;
 }
 
-// Wait for the frame recorded in `sl` and take its timings and counters into ctx->stats.
-int finish_slot(pt_ctx* ctx, FrameSlot& sl) {
+// Wait for the frame recorded in `sl` and take its timings and counters into the lane's statistics.
+int finish_slot(pt_ctx* ctx, Lane& L, FrameSlot& sl) {
     if (!sl.pending) return PT_OK;
     PT_HIP(ctx, hipEventSynchronize(sl.ev1));
     float ms = 0.0f;
@@ -921,50 +1059,65 @@ int finish_slot(pt_ctx* ctx, FrameSlot& sl) {
     PT_HIP(ctx, hipMemcpy(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost));
     float ms_primary = 0.0f;
     PT_HIP(ctx, hipEventElapsedTime(&ms_primary, sl.ev0, sl.evm));
-    if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] frame done: %.3f ms, work / longest chunk %u waves, %u chunks in parts, workgroups wanted %u, other frames running at its start %u\n", ms, c.waves_needed, c.n_split, c.n_groups, c.others_running);
-    ctx->stats.trace_ms = ms;
-    ctx->stats.primary_ms = ms_primary;
-    ctx->stats.paths_ms = ms - ms_primary;
-    ctx->stats.trace_launches = 2;
-    ctx->stats.rays = c.rays + sl.primary_traced;
-    ctx->stats.xforms = c.xforms;
-    ctx->stats.box_tests = c.box_tests;
-    ctx->stats.tri_tests = c.tri_tests;
-    ctx->stats.shades = c.shades;
-    ctx->stats.hits = c.hits;
-    ctx->stats.primary_xforms = ctx->stats.primary_box_tests = ctx->stats.primary_tri_tests = ctx->stats.primary_hits = 0;
+    if (ctx->debug) std::fprintf(stderr, "[pt_amd] frame done: %.3f ms, work / longest chunk %u waves, %u chunks in parts, workgroups wanted %u, other frames running at its start %u\n", ms, c.waves_needed, c.n_split, c.n_groups, c.others_running);
+    PtStats& st = L.stats;
+    st.trace_ms = ms;
+    st.primary_ms = ms_primary;
+    st.paths_ms = ms - ms_primary;
+    st.trace_launches = 2;
+    st.rays = c.rays + sl.primary_traced;
+    st.xforms = c.xforms;
+    st.box_tests = c.box_tests;
+    st.tri_tests = c.tri_tests;
+    st.shades = c.shades;
+    st.hits = c.hits;
+    st.primary_xforms = st.primary_box_tests = st.primary_tri_tests = st.primary_hits = 0;
     if (sl.detail) {
         DCounters k1;
         PT_HIP(ctx, hipMemcpy(&k1, sl.counters_k1.p, sizeof k1, hipMemcpyDeviceToHost));
-        ctx->stats.primary_xforms = k1.xforms;
-        ctx->stats.primary_box_tests = k1.box_tests;
-        ctx->stats.primary_tri_tests = k1.tri_tests;
-        ctx->stats.primary_hits = k1.hits;
+        st.primary_xforms = k1.xforms;
+        st.primary_box_tests = k1.box_tests;
+        st.primary_tri_tests = k1.tri_tests;
+        st.primary_hits = k1.hits;
     }
-    ctx->stats.cycles_refill = c.cyc_refill;
-    ctx->stats.cycles_trace = c.cyc_trace;
-    ctx->stats.cycles_shade = c.cyc_shade;
-    ctx->stats.wave_rounds = c.rounds;
-    ctx->stats.lane_rounds = c.lane_rounds;
-    ctx->stats.object_passes = c.passes;
-    ctx->last_n_paths = c.n_paths;
-    ctx->last_waves_needed = c.waves_needed;
-    ctx->stats.wave_life_sum = c.wave_life_sum;
-    ctx->stats.wave_life_max = c.wave_life_max;
-    ctx->stats.waves = c.waves;
-    for (int k = 0; k < 32; ++k) ctx->stats.wave_life_hist[k] = c.life_hist[k];
-    ctx->stats.paths = sl.paths;
-    ctx->stats.rays_reference = c.rays + sl.primary_traced + sl.primary;
-    ctx->stats.accel_used = (ctx->use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u) | (ctx->tlas_refitted ? 4u : 0u);
+    st.cycles_refill = c.cyc_refill;
+    st.cycles_trace = c.cyc_trace;
+    st.cycles_shade = c.cyc_shade;
+    st.wave_rounds = c.rounds;
+    st.lane_rounds = c.lane_rounds;
+    st.object_passes = c.passes;
+    L.last_n_paths = c.n_paths;
+    L.last_waves_needed = c.waves_needed;
+    st.wave_life_sum = c.wave_life_sum;
+    st.wave_life_max = c.wave_life_max;
+    st.waves = c.waves;
+    for (int k = 0; k < 32; ++k) st.wave_life_hist[k] = c.life_hist[k];
+    st.paths = sl.paths;
+    st.rays_reference = c.rays + sl.primary_traced + sl.primary;
+    st.accel_used = sl.accel_used;
     sl.pending = false;
     return PT_OK;
 }
 
-// All frames in flight, oldest first, so that ctx->stats ends up describing the most recent one.
-int finish_timing(pt_ctx* ctx) {
-    int rc = finish_slot(ctx, ctx->slot[ctx->frame_seq & 1]);
+// The frames in flight of one lane, oldest first, so that its statistics end up describing the most recent one.
+int finish_lane(pt_ctx* ctx, Lane& L) {
+    int rc = finish_slot(ctx, L, L.slot[L.frame_seq & 1]);
     if (rc != PT_OK) return rc;
-    return finish_slot(ctx, ctx->slot[(ctx->frame_seq + 1) & 1]);
+    return finish_slot(ctx, L, L.slot[(L.frame_seq + 1) & 1]);
+}
+
+// Every frame in flight of the context, whichever entry point enqueued it.
+int finish_all(pt_ctx* ctx) {
+    for (Lane& L : ctx->lanes) {
+        if (!L.ready) continue;
+        int rc = finish_lane(ctx, L);
+        if (rc != PT_OK) return rc;
+    }
+    if (ctx->noalloc_pending) {
+        PT_HIP(ctx, hipEventSynchronize(ctx->ev_noalloc));
+        ctx->noalloc_pending = false;
+    }
+    return PT_OK;
 }
 
 // Which closest-hit organisation the frame kernels use, and the LDS layout of the staged scene for PT_MODE_LDS:
@@ -973,13 +1126,14 @@ int finish_timing(pt_ctx* ctx) {
 constexpr uint32_t kLdsSceneMaxBytes = 24 * 1024;
 int scene_mode(const pt_ctx* ctx, LdsScene* ls) {
     std::memset(ls, 0, sizeof *ls);
-    if (ctx->use_tlas) return PT_MODE_TLAS;
-    if (ctx->n_objects == 0 || ctx->n_objects > 32 || ctx->cfg.accel == PT_ACCEL_BRUTE || std::getenv("PT_AMD_NO_LDS_SCENE")) return PT_MODE_LIST;
+    const ObjectSet& os = ctx->sets[ctx->cur_set];
+    if (os.use_tlas) return PT_MODE_TLAS;
+    if (os.n_objects == 0 || os.n_objects > 32 || ctx->cfg.accel == PT_ACCEL_BRUTE || !ctx->lds_scene) return PT_MODE_LIST;
     uint32_t off = 0;
     auto place = [&](uint32_t bytes) { uint32_t o = off; off += (bytes + 15u) & ~15u; return o; };
-    ls->bytes_obj_box = 16u * ctx->n_objects;
-    ls->bytes_objects = (uint32_t)sizeof(DObject) * ctx->n_objects;
-    ls->bytes_l2w = (uint32_t)sizeof(Affine) * ctx->n_objects;
+    ls->bytes_obj_box = 16u * os.n_objects;
+    ls->bytes_objects = (uint32_t)sizeof(DObject) * os.n_objects;
+    ls->bytes_l2w = (uint32_t)sizeof(Affine) * os.n_objects;
     ls->bytes_meshes = (uint32_t)sizeof(DMesh) * ctx->n_meshes;
     ls->bytes_tris = (uint32_t)sizeof(DTri) * ctx->n_tris;
     ls->bytes_tri_ids = ctx->n_blas_nodes ? (uint32_t)sizeof(uint32_t) * ctx->n_tris : 0u;   // only BLAS leaves look at them
@@ -1015,10 +1169,13 @@ struct FrameWork {
     DCounters* counters;
 };
 
-// Enqueue one frame on `s`, image to device memory `out`; with `out16` the image is also packed to binary16 there,
-// inside the span the frame's completion event covers. `noalloc`: the frame works in the device's static array, keeps no
-// record in the context (no statistics, no aux planes to read back, no schedule hints) and nothing is allocated.
-int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uint2* out16 = nullptr, bool noalloc = false) {
+// One thread: takes back what k_chunk_order signed in when the k_paths launch that would have signed it off failed.
+__global__ void k_sign_off() { atomicSub(&g_frames_running, 1u); }
+
+// Enqueue one frame of lane `L` on `s`, image to device memory `out`; with `out16` the image is also packed to binary16
+// there, inside the span the frame's completion event covers. `noalloc`: the frame works in the device's static array,
+// keeps no record in the context (no statistics, no aux planes to read back, no schedule hints) and nothing is allocated.
+int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream_t s, uint2* out16 = nullptr, bool noalloc = false) {
     int rc = check_ready(ctx, "pt_render");
     if (rc != PT_OK) return rc;
     if (f->width == 0 || f->height == 0) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: zero-sized frame");
@@ -1028,16 +1185,29 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
     if (f->settings.samples > (1u << 30)) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: more than 2^30 samples per pixel");
     const size_t n_pix = (size_t)f->width * f->height;
     const size_t n_padded = (size_t)div_up(f->width, 8) * div_up(f->height, 8) * 64;   // whole 8x8 tiles
-    FrameSlot& sl = ctx->slot[ctx->frame_seq & 1];
+    FrameSlot& sl = L.slot[L.frame_seq & 1];
+    const ObjectSet& os = ctx->sets[ctx->cur_set];
     FrameWork w;
+    bool capturing = false;
     if (noalloc) {
         if (!ctx->scratch) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: no work array on this device");
         if (n_padded > kNoallocPix)
             return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: frame larger than PT_NOALLOC_MAX_PIXELS (" + std::to_string(kNoallocPix) +
                                                      " pixels, sizes rounded up to multiples of 8); use pt_render_device");
         if (f->flags != 0u) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: frame flags are not supported");
-        rc = finish_timing(ctx);   // frames of the allocating entry points still in flight: their records are read first
-        if (rc != PT_OK) return rc;
+        // frames of the allocating entry points still in flight: their records are read first (not under stream capture,
+        // where nothing may be waited for: the caller then has to have waited for them)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+        capturing = cap != hipStreamCaptureStatusNone;
+        if (capturing) {
+            for (const Lane& o : ctx->lanes)
+                if (o.slot[0].pending || o.slot[1].pending)
+                    return fail(ctx, PT_ERR_NOT_READY, "pt_render_device_noalloc: frames of the other entry points are pending; wait for them (pt_get_stats) before capturing");
+        } else {
+            rc = finish_all(ctx);
+            if (rc != PT_OK) return rc;
+        }
         unsigned char* b = ctx->scratch;
         w.recs = reinterpret_cast<PathRec*>(b + kScrRecs);
         w.carry = reinterpret_cast<PathCarry*>(b + kScrCarry);
@@ -1048,34 +1218,35 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         w.cost = reinterpret_cast<uint32_t*>(b + kScrCost);
         w.sweeps_done = reinterpret_cast<uint32_t*>(b + kScrSweeps);
         w.counters = reinterpret_cast<DCounters*>(b + kScrCounters);
-        ctx->aux_w = ctx->aux_h = 0;   // the context's aux planes no longer describe the last frame
+        L.aux_w = L.aux_h = 0;   // the lane's aux planes no longer describe the last frame
+        L.hint_valid = false;
     } else {
         // This frame's record replaces the one of the frame before the previous one, which has to be complete; the
         // previous frame may still be running (same stream: its kernels come first). Anything that is not plain
         // back-to-back rendering on one stream waits for everything.
-        const FrameSlot& prev = ctx->slot[(ctx->frame_seq + 1) & 1];
-        if (s != ctx->last_frame_stream || ctx->stats_detail || prev.detail || !ctx->queue_ahead) rc = finish_timing(ctx);
-        else rc = finish_slot(ctx, sl);
+        const FrameSlot& prev = L.slot[(L.frame_seq + 1) & 1];
+        if (s != L.last_frame_stream || ctx->stats_detail || prev.detail || !ctx->queue_ahead) rc = finish_lane(ctx, L);
+        else rc = finish_slot(ctx, L, sl);
         if (rc != PT_OK) return rc;
-        if ((ctx->aux_w != f->width || ctx->aux_h != f->height) && prev.pending) {   // buffers are about to be re-allocated
-            rc = finish_timing(ctx);
+        if ((L.aux_w != f->width || L.aux_h != f->height) && prev.pending) {   // buffers are about to be re-allocated
+            rc = finish_lane(ctx, L);
             if (rc != PT_OK) return rc;
         }
-        PT_HIP(ctx, ctx->d_aux_obj.ensure(4 * n_pix));
-        PT_HIP(ctx, ctx->d_aux_flat.ensure(4 * n_pix));
-        PT_HIP(ctx, ctx->d_aux_t.ensure(4 * n_pix));
-        PT_HIP(ctx, ctx->d_aux_rays.ensure(4 * n_pix));
-        ctx->aux_w = f->width;
-        ctx->aux_h = f->height;
+        PT_HIP(ctx, L.d_aux_obj.ensure(4 * n_pix));
+        PT_HIP(ctx, L.d_aux_flat.ensure(4 * n_pix));
+        PT_HIP(ctx, L.d_aux_t.ensure(4 * n_pix));
+        PT_HIP(ctx, L.d_aux_rays.ensure(4 * n_pix));
+        L.aux_w = f->width;
+        L.aux_h = f->height;
         // path list: at most one entry per pixel (of this partition: sized for the whole frame, partitions are rare)
-        PT_HIP(ctx, ctx->d_paths.ensure(sizeof(PathRec) * n_padded));
-        PT_HIP(ctx, ctx->d_cost.ensure(sizeof(uint32_t) * n_padded));
-        w.aux_obj = ctx->d_aux_obj.as<uint32_t>();
-        w.aux_flat = ctx->d_aux_flat.as<uint32_t>();
-        w.aux_t = ctx->d_aux_t.as<float>();
-        w.aux_rays = ctx->d_aux_rays.as<uint32_t>();
-        w.recs = ctx->d_paths.as<PathRec>();
-        w.cost = ctx->d_cost.as<uint32_t>();
+        PT_HIP(ctx, L.d_paths.ensure(sizeof(PathRec) * n_padded));
+        PT_HIP(ctx, L.d_cost.ensure(sizeof(uint32_t) * n_padded));
+        w.aux_obj = L.d_aux_obj.as<uint32_t>();
+        w.aux_flat = L.d_aux_flat.as<uint32_t>();
+        w.aux_t = L.d_aux_t.as<float>();
+        w.aux_rays = L.d_aux_rays.as<uint32_t>();
+        w.recs = L.d_paths.as<PathRec>();
+        w.cost = L.d_cost.as<uint32_t>();
         w.counters = sl.counters.as<DCounters>();
         w.sweeps_done = nullptr;   // allocated below, when the frame runs in sweeps
         w.carry = nullptr;
@@ -1123,9 +1294,9 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
     } else {
         key.scene_version = 0;
     }
-    const bool use_hint = !noalloc && ctx->hint_valid && std::memcmp(&key, &ctx->hint_key, sizeof key) == 0 && ctx->cost_hints &&
+    const bool use_hint = !noalloc && L.hint_valid && std::memcmp(&key, &L.hint_key, sizeof key) == 0 && ctx->cost_hints &&
                           f->settings.samples >= 8u && f->settings.bounces > 1u;
-    ctx->hint_valid = false;   // until this frame has been enqueued completely
+    if (!noalloc) L.hint_valid = false;   // until this frame has been enqueued completely
     SceneView sv = make_view(ctx);
     const uint32_t depth = stack_depth_needed(ctx);
     const bool st = ctx->stats_detail && !noalloc;
@@ -1144,7 +1315,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
     const int mode = scene_mode(ctx, &ls);
     {
         const size_t scene_lds = (mode == PT_MODE_LDS ? ls.total_bytes : 0u);
-        const bool wide = (size_t)16 * depth * 256 + scene_lds <= 64 * 1024 && !std::getenv("PT_AMD_K1_NARROW");   // 16 waves per workgroup when their stacks fit
+        const bool wide = (size_t)16 * depth * 256 + scene_lds <= 64 * 1024 && !ctx->k1_narrow;   // 16 waves per workgroup when their stacks fit
         const uint32_t waves = wide ? 16u : 4u;
         const size_t lds = (size_t)waves * depth * 64 * sizeof(uint32_t) + scene_lds;
         const uint32_t grid = (wide && pc == 1u) ? div_up(fp.tiles_x, 4) * div_up(fp.tiles_y, 4) : div_up(fp.n_local_tiles, waves);
@@ -1172,7 +1343,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         pp.samples = fp.samples;
         pp.chunk = ctx->chunk_pixels;
         // few objects: keep a wave on one tile's worth of pixels at a time (similar candidates); many objects: keep every lane busy
-        pp.refill_min = ctx->refill_min ? ctx->refill_min : (ctx->use_tlas ? 1u : 64u);
+        pp.refill_min = ctx->refill_min ? ctx->refill_min : (os.use_tlas ? 1u : 64u);
         // PT_MODE_TLAS: the first lds_stack_max entries of a lane's traversal stack live in LDS, the rest (seldom reached)
         // in global memory, so that the stack does not decide how many workgroups a compute unit holds
         const uint32_t depth_paths = (mode == PT_MODE_TLAS && !noalloc) ? std::min(depth, ctx->lds_stack_max) : depth;
@@ -1193,7 +1364,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         int paths_mode = mode;
         // Only when the last finished frame of this view listed so few pixels that one workgroup per compute unit
         // takes them all anyway (a frame full of such pixels is better served by more workgroups).
-        if (mode == PT_MODE_LIST && ctx->lds_blas && use_hint && ctx->last_n_paths <= (uint64_t)ctx->n_cus * 256u * 4u) {
+        if (mode == PT_MODE_LIST && ctx->lds_blas && use_hint && L.last_n_paths <= (uint64_t)ctx->n_cus * 256u * 4u) {
             const size_t budget = (size_t)ctx->lds_per_cu > lds + 1024 ? (size_t)ctx->lds_per_cu - 1024 - lds : 0;
             uint32_t best = PT_NONE;
             for (uint32_t m = 0; m < ctx->n_meshes; ++m) {
@@ -1208,7 +1379,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
                 // its triangle records too, if two workgroups still fit on a compute unit then (two waves per SIMD hide each
                 // other's LDS and memory waits; one wave alone does not: scene.glb 17.0 against 20.2 ms per frame)
                 const size_t with_tris = lds + lds_blas_bytes(lb.n_nodes, ctx->h_meshes[best].tri_count);
-                lb.n_tris = (2 * with_tris + 2048 <= (size_t)ctx->lds_per_cu && !std::getenv("PT_AMD_LDS_BLAS_NODES_ONLY")) ? ctx->h_meshes[best].tri_count : 0u;
+                lb.n_tris = (2 * with_tris + 2048 <= (size_t)ctx->lds_per_cu && !ctx->lds_blas_nodes_only) ? ctx->h_meshes[best].tri_count : 0u;
                 paths_mode = PT_MODE_LIST_LB;
             }
         }
@@ -1218,7 +1389,7 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
             // as many as fit without costing a workgroup per compute unit (registers allow four)
             const size_t share = ctx->lds_per_cu / 4 - 512;
             const uint32_t fit = share > lds ? (uint32_t)((share - lds) / sizeof(WNode)) : 0u;
-            pp.tlas_top_n = std::min(ctx->tlas_n_wide, ctx->tlas_top_max == PT_NONE ? fit : ctx->tlas_top_max);
+            pp.tlas_top_n = std::min(os.tlas_n_wide, ctx->tlas_top_max == PT_NONE ? fit : ctx->tlas_top_max);
         }
         const size_t lds_paths = lds + (paths_mode == PT_MODE_LIST_LB ? lds_blas_bytes(lb.n_nodes, lb.n_tris) : 0u) + (size_t)pp.tlas_top_n * sizeof(WNode);
         // Object-list scenes whose last finished frame had work for few waves (the sum of its chunk lengths over the longest:
@@ -1226,14 +1397,14 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         bool roomy = false;
         if (paths_mode == PT_MODE_LIST || paths_mode == PT_MODE_LIST_LB) {
             const uint64_t roomy_waves = (uint64_t)ctx->n_cus * 4u * PT_PATHS_MIN_WAVES_LIST_ROOMY;
-            roomy = ctx->list_regs == 2 || (ctx->list_regs == 0 && use_hint && ctx->last_waves_needed != 0u && (uint64_t)ctx->last_waves_needed <= 2u * roomy_waves);
+            roomy = ctx->list_regs == 2 || (ctx->list_regs == 0 && use_hint && L.last_waves_needed != 0u && (uint64_t)L.last_waves_needed <= 2u * roomy_waves);
         }
         PathsFn fn = (roomy ? ptable_roomy : ptable)[paths_mode][st ? 1 : 0];
         if (lds_paths > 64 * 1024) PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_paths));
         int per_cu = 0;
         PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds_paths));
         if (per_cu < 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: the path kernel does not fit on a compute unit with this traversal stack");
-        if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
+        if (ctx->blocks_per_cu >= 1 && ctx->blocks_per_cu <= per_cu) per_cu = ctx->blocks_per_cu;
         const uint32_t grid = std::min(div_up(fp.n_local_tiles, 4), (uint32_t)per_cu * ctx->n_cus);
         // Sample slices ("sweeps"): half of the samples, then a quarter, ... so that the items handed out last are
         // short. Only with whole-chunk refill (a wave then owns one chunk at a time and can report it complete).
@@ -1256,47 +1427,68 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
         if (pp.n_sweeps > 1u) {
             const size_t bytes = sizeof(uint32_t) * (size_t)fp.n_local_tiles;   // one flag per chunk of 64 entries
             if (!noalloc) {
-                PT_HIP(ctx, ctx->d_sweeps_done.ensure(bytes));
-                PT_HIP(ctx, ctx->d_carry.ensure(sizeof(PathCarry) * (size_t)fp.n_local_tiles * 64));
-                w.sweeps_done = ctx->d_sweeps_done.as<uint32_t>();
-                w.carry = ctx->d_carry.as<PathCarry>();
+                PT_HIP(ctx, L.d_sweeps_done.ensure(bytes));
+                PT_HIP(ctx, L.d_carry.ensure(sizeof(PathCarry) * (size_t)fp.n_local_tiles * 64));
+                w.sweeps_done = L.d_sweeps_done.as<uint32_t>();
+                w.carry = L.d_carry.as<PathCarry>();
             }
             PT_HIP(ctx, hipMemsetAsync(w.sweeps_done, 0, bytes, s));
         }
         uint4* wlog = nullptr;
-        ctx->wave_log_records = 0;
+        if (!noalloc) L.wave_log_records = 0;
         if (st) {
-            PT_HIP(ctx, ctx->d_wave_log.ensure((size_t)64 * grid * 4));
-            PT_HIP(ctx, hipMemsetAsync(ctx->d_wave_log.p, 0, (size_t)64 * grid * 4, s));
-            wlog = ctx->d_wave_log.as<uint4>();
-            ctx->wave_log_records = grid * 4u;
+            PT_HIP(ctx, L.d_wave_log.ensure((size_t)64 * grid * 4));
+            PT_HIP(ctx, hipMemsetAsync(L.d_wave_log.p, 0, (size_t)64 * grid * 4, s));
+            wlog = L.d_wave_log.as<uint4>();
+            L.wave_log_records = grid * 4u;
         }
-        if (std::getenv("PT_AMD_DEBUG")) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d roomy=%d per_cu=%d grid=%u lds=%zu depth=%u/%u tlas: nodes=%u levels=%u need=%u top=%u chunk=%u refill_min=%u sweeps=%u last_n_paths=%llu\n", paths_mode, (int)roomy, per_cu, grid, lds_paths, depth_paths, depth, ctx->tlas_n_wide, ctx->tlas_depth, ctx->tlas_need, pp.tlas_top_n, pp.chunk, pp.refill_min, pp.n_sweeps, (unsigned long long)ctx->last_n_paths);
+        if (ctx->debug) std::fprintf(stderr, "[pt_amd] k_paths: mode=%d roomy=%d per_cu=%d grid=%u lds=%zu depth=%u/%u tlas: nodes=%u levels=%u need=%u top=%u chunk=%u refill_min=%u sweeps=%u last_n_paths=%llu\n", paths_mode, (int)roomy, per_cu, grid, lds_paths, depth_paths, depth, os.tlas_n_wide, os.tlas_depth, os.tlas_need, pp.tlas_top_n, pp.chunk, pp.refill_min, pp.n_sweeps, (unsigned long long)L.last_n_paths);
+        // (everything that can fail comes before k_chunk_order, which signs the frame in as running on the device)
+        pp.stack_overflow = nullptr;
+        if (depth_paths < depth) {
+            PT_HIP(ctx, L.d_stack_overflow.ensure(sizeof(uint32_t) * (size_t)(depth - depth_paths) * grid * 256));
+            pp.stack_overflow = L.d_stack_overflow.as<uint32_t>();
+        }
         const uint32_t* chunk_order = nullptr;
         const ChunkOrderInfo* order_info = nullptr;
         if (use_hint && pp.chunk == PT_CHUNK) {
             const uint32_t max_chunks = fp.n_local_tiles;   // 64 entries per tile at most
-            PT_HIP(ctx, ctx->d_chunk_bin.ensure(sizeof(uint32_t) * max_chunks));
-            PT_HIP(ctx, ctx->d_chunk_order.ensure(sizeof(uint32_t) * max_chunks + sizeof(ChunkOrderInfo)));
-            uint32_t* order = ctx->d_chunk_order.as<uint32_t>();
+            PT_HIP(ctx, L.d_chunk_bin.ensure(sizeof(uint32_t) * max_chunks));
+            PT_HIP(ctx, L.d_chunk_order.ensure(sizeof(uint32_t) * max_chunks + sizeof(ChunkOrderInfo)));
+            uint32_t* order = L.d_chunk_order.as<uint32_t>();
             ChunkOrderInfo* info = reinterpret_cast<ChunkOrderInfo*>(order + max_chunks);
-            k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(w.cost, dc, fp.samples, ctx->d_chunk_bin.as<uint32_t>());
-            k_chunk_order<<<1, 1024, 0, s>>>(ctx->d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction[0], ctx->split_fraction[1], ctx->group_margin_8ths[0], ctx->group_margin_8ths[1], ctx->n_cus, grid * 4u, ctx->split_load_8ths);
-            chunk_order = order;
-            order_info = info;
-        }
-        pp.stack_overflow = nullptr;
-        if (depth_paths < depth) {
-            PT_HIP(ctx, ctx->d_stack_overflow.ensure(sizeof(uint32_t) * (size_t)(depth - depth_paths) * grid * 256));
-            pp.stack_overflow = ctx->d_stack_overflow.as<uint32_t>();
+            k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(w.cost, dc, fp.samples, L.d_chunk_bin.as<uint32_t>());
+            PT_HIP(ctx, hipGetLastError());
+            k_chunk_order<<<1, 1024, 0, s>>>(L.d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction[0], ctx->split_fraction[1], ctx->group_margin_8ths[0], ctx->group_margin_8ths[1], ctx->n_cus, grid * 4u, ctx->split_load_8ths);
+            if (hipGetLastError() == hipSuccess) {   // (not launched: the frame was not signed in and runs in list order)
+                chunk_order = order;
+                order_info = info;
+            }
         }
         fn<<<grid, 256, lds_paths, s>>>(PT_SCENE_ARGS(sv), ls, lb, pp, depth_paths, recs, w.carry, w.sweeps_done, chunk_order,
                                   order_info, o4, ar, dc, wlog);
-        PT_HIP(ctx, hipGetLastError());
+        {
+            const hipError_t e_launch = hipGetLastError();
+            if (e_launch != hipSuccess) {
+                // the last wave of k_paths would have signed the frame off: do it for it, or every later frame of the process
+                // on this device would be scheduled as sharing it
+                if (chunk_order) k_sign_off<<<1, 1, 0, s>>>();
+                (void)hipGetLastError();
+                return fail(ctx, PT_ERR_DEVICE, std::string("pt_render: k_paths launch: ") + hipGetErrorString(e_launch));
+            }
+        }
     }
-    if (noalloc) return PT_OK;   // (no record of this frame is kept; hint_valid stays false)
-    ctx->hint_key = key;
-    ctx->hint_valid = f->settings.samples > 0u && f->settings.bounces > 0u;
+    if (noalloc) {
+        // (no record of this frame is kept; the event lets uploads and pt_destroy wait for it -- recording allocates nothing)
+        if (!capturing) {
+            PT_HIP(ctx, hipEventRecord(ctx->ev_noalloc, s));
+            ctx->noalloc_pending = true;
+            ctx->noalloc_set = ctx->cur_set;
+        }
+        return PT_OK;
+    }
+    L.hint_key = key;
+    L.hint_valid = f->settings.samples > 0u && f->settings.bounces > 0u;
     // pixels of this partition
     uint64_t local_pixels = 0;
     if (pc == 1) {
@@ -1313,8 +1505,16 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
     sl.primary_traced = (fp.bounces > 0 && fp.samples > 0) ? local_pixels : 0;  // one primary ray per pixel (k_primary)
 
     if (f->flags & (PT_FRAME_ACCUMULATE | PT_FRAME_RESET)) {
+        // One accumulation buffer per context; frames add to it in the order they were enqueued, whichever streams they
+        // run on (an f32 sum depends on its order): each waits for the previous one's addition.
+        const bool restart = (f->flags & PT_FRAME_RESET) || ctx->acc_w != f->width || ctx->acc_h != f->height || ctx->acc_frames == 0;
+        if (ctx->acc_pending && ctx->acc_stream != s) {
+            if (restart && ctx->d_acc.cap < 16 * n_pix) PT_HIP(ctx, hipEventSynchronize(ctx->ev_acc));   // about to be re-allocated
+            else PT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_acc, 0));
+        }
         // (acc_frames == 0: nothing accumulated yet, or the scene changed since: the old sum belongs to another scene)
-        if ((f->flags & PT_FRAME_RESET) || ctx->acc_w != f->width || ctx->acc_h != f->height || ctx->acc_frames == 0) {
+        if (restart) {
+            if (ctx->d_acc.cap < 16 * n_pix && ctx->acc_pending) PT_HIP(ctx, hipEventSynchronize(ctx->ev_acc));
             PT_HIP(ctx, ctx->d_acc.ensure(16 * n_pix));
             PT_HIP(ctx, hipMemsetAsync(ctx->d_acc.p, 0, 16 * n_pix, s));
             ctx->acc_w = f->width;
@@ -1327,6 +1527,9 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
                                                                       (uint32_t)n_pix, (float)ctx->acc_frames);
             PT_HIP(ctx, hipGetLastError());
         }
+        PT_HIP(ctx, hipEventRecord(ctx->ev_acc, s));
+        ctx->acc_pending = true;
+        ctx->acc_stream = s;
     }
     if (out16) {
         k_pack_f16<<<div_up((uint32_t)n_pix, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(out), out16, (uint32_t)n_pix);
@@ -1334,8 +1537,10 @@ int render_enqueue(pt_ctx* ctx, const PtFrame* f, float* out, hipStream_t s, uin
     }
     PT_HIP(ctx, hipEventRecord(sl.ev1, s));
     sl.pending = true;
-    ctx->frame_seq++;
-    ctx->last_frame_stream = s;
+    sl.obj_set = ctx->cur_set;
+    sl.accel_used = (os.use_tlas ? 1u : 0u) | (ctx->n_blas_nodes ? 2u : 0u) | (os.refitted ? 4u : 0u);
+    L.frame_seq++;
+    L.last_frame_stream = s;
     return PT_OK;
 }
 
@@ -1348,16 +1553,19 @@ int pt_render_device(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_device, v
     try {
         if (!frame || !out_rgba_device) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_device: null argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
+        Lane& L = ctx->lanes[0];
         hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
         if (frame->flags & PT_FRAME_OUTPUT_F16) {
             const size_t n_pix = (size_t)frame->width * frame->height;
-            PT_HIP(ctx, ctx->d_out.ensure(16 * n_pix));
-            int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), s, reinterpret_cast<uint2*>(out_rgba_device));
+            if (L.d_out.cap < 16 * n_pix) { int rc = finish_lane(ctx, L); if (rc != PT_OK) return rc; }   // (a frame in flight may still write the old one)
+            PT_HIP(ctx, L.d_out.ensure(16 * n_pix));
+            int rc = render_enqueue(ctx, L, frame, L.d_out.as<float>(), s, reinterpret_cast<uint2*>(out_rgba_device));
             if (rc != PT_OK) return rc;
         } else {
-            int rc = render_enqueue(ctx, frame, reinterpret_cast<float*>(out_rgba_device), s);
+            int rc = render_enqueue(ctx, L, frame, reinterpret_cast<float*>(out_rgba_device), s);
             if (rc != PT_OK) return rc;
         }
+        ctx->cur_lane = 0;
         if (!hip_stream) PT_HIP(ctx, hipStreamSynchronize(s));
         return PT_OK;
     } catch (...) {
@@ -1371,8 +1579,9 @@ int pt_render_device_noalloc(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_d
         if (!frame || !out_rgba_device) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_device_noalloc: null argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
         hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
-        int rc = render_enqueue(ctx, frame, reinterpret_cast<float*>(out_rgba_device), s, nullptr, true);
+        int rc = render_enqueue(ctx, ctx->lanes[0], frame, reinterpret_cast<float*>(out_rgba_device), s, nullptr, true);
         if (rc != PT_OK) return rc;
+        ctx->cur_lane = 0;
         if (!hip_stream) PT_HIP(ctx, hipStreamSynchronize(s));
         return PT_OK;
     } catch (...) {
@@ -1385,19 +1594,98 @@ int pt_render(pt_ctx* ctx, const PtFrame* frame, void* out_rgba_host) {
     try {
         if (!frame || !out_rgba_host) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render: null argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
+        Lane& L = ctx->lanes[0];
         const size_t n_pix = (size_t)frame->width * frame->height;
         const bool f16 = (frame->flags & PT_FRAME_OUTPUT_F16) != 0;
         const size_t out_bytes = (f16 ? 8 : 16) * n_pix;
-        PT_HIP(ctx, ctx->d_out.ensure(16 * n_pix));
-        if (f16) PT_HIP(ctx, ctx->d_out16.ensure(8 * n_pix));
-        int rc = render_enqueue(ctx, frame, ctx->d_out.as<float>(), ctx->stream, f16 ? ctx->d_out16.as<uint2>() : nullptr);
+        if (L.d_out.cap < 16 * n_pix || (f16 && L.d_out16.cap < 8 * n_pix)) { int rc = finish_lane(ctx, L); if (rc != PT_OK) return rc; }
+        PT_HIP(ctx, L.d_out.ensure(16 * n_pix));
+        if (f16) PT_HIP(ctx, L.d_out16.ensure(8 * n_pix));
+        int rc = render_enqueue(ctx, L, frame, L.d_out.as<float>(), ctx->stream, f16 ? L.d_out16.as<uint2>() : nullptr);
         if (rc != PT_OK) return rc;
-        const void* src = f16 ? ctx->d_out16.p : ctx->d_out.p;
+        ctx->cur_lane = 0;
+        const void* src = f16 ? L.d_out16.p : L.d_out.p;
         PT_HIP(ctx, hipMemcpyAsync(out_rgba_host, src, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return PT_OK;
     } catch (...) {
         return fail(ctx, PT_ERR_DEVICE, "pt_render: unexpected exception");
+    }
+}
+
+}  // extern "C"
+
+namespace {
+
+// pt_render_submit / pt_render_submit_device: the frame goes onto the stream of lane 1 + slot; `host` or `device` (one of
+// them) receives the image behind it on that stream.
+int submit_frame(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* host, void* device, const char* who) {
+    if (!frame) return fail(ctx, PT_ERR_INVALID_ARGUMENT, std::string(who) + ": null argument");
+    if (slot >= kMaxFrameSlots) return fail(ctx, PT_ERR_INVALID_ARGUMENT, std::string(who) + ": slot >= PT_MAX_FRAME_SLOTS");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    Lane& L = ctx->lanes[1u + slot];
+    if (L.submitted) return fail(ctx, PT_ERR_INVALID_ARGUMENT, std::string(who) + ": slot " + std::to_string(slot) + " holds a frame that has not been waited for (pt_render_wait)");
+    if (!L.ready) {
+        const hipError_t e = lane_init(ctx, L, true);
+        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, std::string(who) + ": " + hipGetErrorString(e));
+    }
+    const size_t n_pix = (size_t)frame->width * frame->height;
+    const bool f16 = (frame->flags & PT_FRAME_OUTPUT_F16) != 0;
+    // (the slot's previous frame has been waited for, so its image buffers are free to be re-allocated)
+    float* out32 = static_cast<float*>(device);
+    uint2* out16 = nullptr;
+    if (!device || f16) {
+        PT_HIP(ctx, L.d_out.ensure(16 * n_pix));
+        out32 = L.d_out.as<float>();
+    }
+    if (f16) {
+        if (device) out16 = static_cast<uint2*>(device);
+        else { PT_HIP(ctx, L.d_out16.ensure(8 * n_pix)); out16 = L.d_out16.as<uint2>(); }
+    }
+    int rc = render_enqueue(ctx, L, frame, out32, L.stream, out16);
+    if (rc != PT_OK) return rc;
+    if (host) PT_HIP(ctx, hipMemcpyAsync(host, f16 ? static_cast<const void*>(out16) : static_cast<const void*>(out32), (f16 ? 8 : 16) * n_pix, hipMemcpyDeviceToHost, L.stream));
+    L.submitted = true;
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_render_submit(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* out_rgba_host) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!out_rgba_host) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_submit: null argument");
+        return submit_frame(ctx, frame, slot, out_rgba_host, nullptr, "pt_render_submit");
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_render_submit: unexpected exception");
+    }
+}
+
+int pt_render_submit_device(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* out_rgba_device) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!out_rgba_device) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_submit_device: null argument");
+        return submit_frame(ctx, frame, slot, nullptr, out_rgba_device, "pt_render_submit_device");
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_render_submit_device: unexpected exception");
+    }
+}
+
+int pt_render_wait(pt_ctx* ctx, uint32_t slot) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (slot >= kMaxFrameSlots) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_wait: slot >= PT_MAX_FRAME_SLOTS");
+        Lane& L = ctx->lanes[1u + slot];
+        if (!L.submitted) return fail(ctx, PT_ERR_NOT_READY, "pt_render_wait: no frame has been submitted to slot " + std::to_string(slot));
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        L.submitted = false;   // (whatever happens below, the slot can be submitted to again)
+        PT_HIP(ctx, hipStreamSynchronize(L.stream));
+        ctx->cur_lane = 1u + slot;
+        return finish_lane(ctx, L);
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_render_wait: unexpected exception");
     }
 }
 
@@ -1463,19 +1751,20 @@ int pt_read_aux(pt_ctx* ctx, uint32_t kind, void* out_host, size_t out_bytes) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
         if (!out_host) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_read_aux: null argument");
-        if (ctx->aux_w == 0) return fail(ctx, PT_ERR_NOT_READY, "pt_read_aux: no frame has been rendered");
-        const size_t need = (size_t)4 * ctx->aux_w * ctx->aux_h;
+        Lane& L = ctx->lanes[ctx->cur_lane];
+        if (L.aux_w == 0) return fail(ctx, PT_ERR_NOT_READY, "pt_read_aux: no frame has been rendered");
+        const size_t need = (size_t)4 * L.aux_w * L.aux_h;
         if (out_bytes < need) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_read_aux: buffer too small");
         const DevBuf* src = nullptr;
         switch (kind) {
-            case PT_AUX_PRIMARY_OBJECT: src = &ctx->d_aux_obj; break;
-            case PT_AUX_PRIMARY_FLAT_ID: src = &ctx->d_aux_flat; break;
-            case PT_AUX_PRIMARY_T: src = &ctx->d_aux_t; break;
-            case PT_AUX_RAY_COUNT: src = &ctx->d_aux_rays; break;
+            case PT_AUX_PRIMARY_OBJECT: src = &L.d_aux_obj; break;
+            case PT_AUX_PRIMARY_FLAT_ID: src = &L.d_aux_flat; break;
+            case PT_AUX_PRIMARY_T: src = &L.d_aux_t; break;
+            case PT_AUX_RAY_COUNT: src = &L.d_aux_rays; break;
             default: return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_read_aux: unknown kind");
         }
         PT_HIP(ctx, hipSetDevice(ctx->device));
-        int rc = finish_timing(ctx);
+        int rc = finish_lane(ctx, L);
         if (rc != PT_OK) return rc;
         PT_HIP(ctx, hipMemcpy(out_host, src->p, need, hipMemcpyDeviceToHost));
         return PT_OK;
@@ -1489,11 +1778,12 @@ int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n
     try {
         if (!n_records) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_debug_wave_log: null argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
-        int rc = finish_timing(ctx);
+        Lane& L = ctx->lanes[ctx->cur_lane];
+        int rc = finish_lane(ctx, L);
         if (rc != PT_OK) return rc;
-        *n_records = ctx->wave_log_records;
-        const size_t bytes = std::min(out_bytes, (size_t)64 * ctx->wave_log_records);
-        if (out_host && bytes) PT_HIP(ctx, hipMemcpy(out_host, ctx->d_wave_log.p, bytes, hipMemcpyDeviceToHost));
+        *n_records = L.wave_log_records;
+        const size_t bytes = std::min(out_bytes, (size_t)64 * L.wave_log_records);
+        if (out_host && bytes) PT_HIP(ctx, hipMemcpy(out_host, L.d_wave_log.p, bytes, hipMemcpyDeviceToHost));
         return PT_OK;
     } catch (...) {
         return fail(ctx, PT_ERR_DEVICE, "pt_debug_wave_log: unexpected exception");
@@ -1511,9 +1801,12 @@ int pt_get_stats(pt_ctx* ctx, PtStats* out) {
     try {
         if (!out) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_get_stats: null argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
-        int rc = finish_timing(ctx);
+        // every frame in flight is waited for (this is also how a caller of pt_render_device learns that its frames are done);
+        // the numbers are those of the lane whose frame was completed last through pt_render* / pt_render_wait
+        int rc = finish_all(ctx);
         if (rc != PT_OK) return rc;
-        *out = ctx->stats;
+        *out = ctx->lanes[ctx->cur_lane].stats;
+        out->build_ms = ctx->build_ms;
         return PT_OK;
     } catch (...) {
         return fail(ctx, PT_ERR_DEVICE, "pt_get_stats: unexpected exception");
@@ -1542,15 +1835,16 @@ int pt_debug_check_accel(pt_ctx* ctx, uint32_t* n_errors, uint32_t* tlas_depth, 
                 want_leaves += ctx->h_meshes[m].tri_count;
             }
         }
-        if (ctx->use_tlas && ctx->n_objects > 1) {
-            k_check_bvh<<<div_up(ctx->n_objects - 1, 256), 256, 0, s>>>(ctx->d_tlas_bnodes.as<BvhNode>(), 0, ctx->n_objects - 1,
-                                                                        ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, nullptr,
-                                                                        ctx->t_errors.as<uint32_t>());
-            if (ctx->tlas_n_wide) {
-                k_check_wide<<<div_up(ctx->tlas_n_wide, 256), 256, 0, s>>>(ctx->d_tlas_nodes.as<WNode>(), 0, ctx->tlas_n_wide, ctx->d_tlas_bnodes.as<BvhNode>(),
-                                                                           ctx->d_obj_lo.as<float4>(), ctx->d_obj_hi.as<float4>(), 0, nullptr,
-                                                                           ctx->t_errors.as<uint32_t>());
-                want_leaves += ctx->n_objects;
+        const ObjectSet& os = ctx->sets[ctx->cur_set];
+        if (os.built && os.use_tlas && os.n_objects > 1) {
+            k_check_bvh<<<div_up(os.n_objects - 1, 256), 256, 0, s>>>(ctx->d_tlas_bnodes.as<BvhNode>(), 0, os.n_objects - 1,
+                                                                      os.d_obj_lo.as<float4>(), os.d_obj_hi.as<float4>(), 0, nullptr,
+                                                                      ctx->t_errors.as<uint32_t>());
+            if (os.tlas_n_wide) {
+                k_check_wide<<<div_up(os.tlas_n_wide, 256), 256, 0, s>>>(os.d_tlas_nodes.as<WNode>(), 0, os.tlas_n_wide, ctx->d_tlas_bnodes.as<BvhNode>(),
+                                                                         os.d_obj_lo.as<float4>(), os.d_obj_hi.as<float4>(), 0, nullptr,
+                                                                         ctx->t_errors.as<uint32_t>());
+                want_leaves += os.n_objects;
             }
         }
         PT_HIP(ctx, hipGetLastError());
@@ -1558,7 +1852,7 @@ int pt_debug_check_accel(pt_ctx* ctx, uint32_t* n_errors, uint32_t* tlas_depth, 
         PT_HIP(ctx, hipMemcpyAsync(found, ctx->t_errors.p, sizeof found, hipMemcpyDeviceToHost, s));
         PT_HIP(ctx, hipStreamSynchronize(s));
         *n_errors = found[0] + (found[1] == want_leaves ? 0u : 1u);   // every primitive in exactly one leaf
-        if (tlas_depth) *tlas_depth = ctx->use_tlas ? ctx->tlas_depth : 0;
+        if (tlas_depth) *tlas_depth = os.use_tlas ? os.tlas_depth : 0;
         if (max_blas_depth) *max_blas_depth = ctx->max_blas_depth;
         return PT_OK;
     } catch (...) {

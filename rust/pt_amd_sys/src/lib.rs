@@ -170,6 +170,7 @@ pub const PT_MULTI_VIRTUAL_FRAMES: u32 = 1;
 pub const PT_MULTI_FLAG_HOST_SUM: u32 = 0x1;
 pub const PT_MULTI_FLAG_FORCE_COLLECTIVE: u32 = 0x2;
 pub const PT_NOALLOC_MAX_PIXELS: u32 = 262144;
+pub const PT_MAX_FRAME_SLOTS: u32 = 8;
 
 /// Several GPUs behind one handle (pt_multi_*): device list, partition mode, accel and tie rule for every GPU.
 #[repr(C)]
@@ -203,6 +204,11 @@ extern "C" {
     pub fn pt_render_device(ctx: *mut pt_ctx, frame: *const PtFrame, out_rgba_device: *mut c_void, hip_stream: *mut c_void) -> c_int;
     /// The same frame without device-memory allocation (frames of at most PT_NOALLOC_MAX_PIXELS pixels).
     pub fn pt_render_device_noalloc(ctx: *mut pt_ctx, frame: *const PtFrame, out_rgba_device: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    /// Frames in flight on one context: enqueue on `slot` (0..PT_MAX_FRAME_SLOTS), image copied to `out_rgba_host` behind the frame.
+    pub fn pt_render_submit(ctx: *mut pt_ctx, frame: *const PtFrame, slot: u32, out_rgba_host: *mut c_void) -> c_int;
+    pub fn pt_render_submit_device(ctx: *mut pt_ctx, frame: *const PtFrame, slot: u32, out_rgba_device: *mut c_void) -> c_int;
+    /// Blocks until the frame submitted to `slot` (and its copy) is complete.
+    pub fn pt_render_wait(ctx: *mut pt_ctx, slot: u32) -> c_int;
     pub fn pt_multi_create(cfg: *const PtMultiConfig, out: *mut *mut pt_multi) -> c_int;
     pub fn pt_multi_destroy(m: *mut pt_multi) -> c_int;
     pub fn pt_multi_last_error(m: *const pt_multi) -> *const c_char;
@@ -301,6 +307,25 @@ impl Context {
         let mut f = *frame;
         f.flags |= PT_FRAME_OUTPUT_F16;
         let rc = unsafe { pt_render(self.raw, &f, out.as_mut_ptr() as *mut c_void) };
+        self.check(rc)
+    }
+
+    /// Enqueues a frame on `slot` and returns; the binary16 image is in `out` once `wait(slot)` has returned. `out` must be
+    /// page-locked memory from `host_alloc` that stays valid until then (hence the raw pointer): `width * height * 4` u16.
+    /// A render node that keeps K frames in flight submits frame n to slot n % K and waits for frame n - K + 1.
+    ///
+    /// # Safety
+    /// `out` must point to at least `width * height * 8` writable bytes that outlive the matching `wait`.
+    pub unsafe fn submit_f16(&mut self, frame: &PtFrame, slot: u32, out: *mut u16) -> Result<(), PtError> {
+        let mut f = *frame;
+        f.flags |= PT_FRAME_OUTPUT_F16;
+        let rc = pt_render_submit(self.raw, &f, slot, out as *mut c_void);
+        self.check(rc)
+    }
+
+    /// Blocks until the frame submitted to `slot` is complete.
+    pub fn wait(&mut self, slot: u32) -> Result<(), PtError> {
+        let rc = unsafe { pt_render_wait(self.raw, slot) };
         self.check(rc)
     }
 

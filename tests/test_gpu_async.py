@@ -1,0 +1,203 @@
+"""Frames in flight on ONE context (pt_render_submit / pt_render_submit_device / pt_render_wait), through the C ABI.
+
+The asynchronous pair stands where `RayTraceNode::run` stands in the reference (src/shader.rs:121-213: the pass is
+recorded, the renderer submits it later). Whatever the number of frames in flight, every image, aux plane and ray
+count must be the one the synchronous call gives, i.e. the CPU restatement's, bit for bit; object uploads between
+submits (extract_visible rewrites the objects every frame, src/extract.rs:297-346) must not disturb frames already
+submitted; accumulated frames add up in submit order.
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from path_tracing_amd import abi, scenes
+from tests.oracle_lib import oracle_render
+
+pytestmark = pytest.mark.gpu
+
+TIMES = [0.0, 1.5, 2.5, 3.5, 0.5, 4.5, 5.5]
+
+
+def _scene(name):
+    return {"cornell": lambda: scenes.cornell_box(96, 64, 8, 10),                      # staged in LDS, sample sweeps
+            "boxes": lambda: scenes.boxes(128, 72, 16, 10),
+            "glb": lambda: scenes.scene_glb_textured(96, 56, 8, 10),                    # object list + BLAS
+            "instanced": lambda: scenes.instanced_boxes(n_objects=600, width=96, height=64, samples=4, extent=6.0)}[name]()   # TLAS
+
+
+@pytest.mark.parametrize("name", ["cornell", "boxes", "glb", "instanced"])
+@pytest.mark.parametrize("in_flight", [1, 3, 8])
+def test_frames_in_flight_match_the_oracle(name, in_flight):
+    scene = _scene(name)
+    refs = [oracle_render(scene, scene.frame(time=t)) for t in TIMES]
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        bufs = [ctx.host_array((scene.height, scene.width, 4), np.float32) for _ in range(in_flight)]
+        done = 0
+        for i, t in enumerate(TIMES + [None] * in_flight):
+            slot = i % in_flight
+            if i >= in_flight:      # the frame submitted `in_flight` steps ago
+                j = i - in_flight
+                ctx.wait(slot)
+                ref = refs[j]
+                assert np.array_equal(bufs[slot].view(np.uint32), ref["image"].view(np.uint32)), f"frame {j}"
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID), ref["primary_flat_id"]), f"frame {j}"
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_OBJECT), ref["primary_object"]), f"frame {j}"
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), ref["ray_count"]), f"frame {j}"
+                assert ctx.stats()["rays_reference"] == int(ref["ray_count"].astype(np.uint64).sum())
+                done += 1
+            if t is not None:
+                bufs[slot][...] = -1.0
+                ctx.upload_objects(scene.objects)      # the unchanged array, every frame, as the reference hands it over
+                ctx.submit(scene.frame(time=t), slot, bufs[slot])
+        assert done == len(TIMES)
+        # the synchronous entry point on the same context afterwards
+        assert np.array_equal(ctx.render(scene.frame(time=TIMES[1])).view(np.uint32), refs[1]["image"].view(np.uint32))
+
+
+def test_f16_and_device_outputs_of_submitted_frames():
+    import ctypes as C
+    scene = scenes.cornell_box(64, 48, 4, 10)
+    ref = oracle_render(scene, scene.frame())["image"]
+    abi.load_library()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    d32, d16 = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d32), ref.nbytes) == 0 and hip.hipMalloc(C.byref(d16), ref.nbytes // 2) == 0
+    try:
+        with abi.Context() as ctx:
+            ctx.upload_scene(scene)
+            half = ctx.host_array(ref.shape, np.float16)
+            ctx.submit(scene.frame(flags=abi.PT_FRAME_OUTPUT_F16), 0, half)
+            ctx.submit_device(scene.frame(), 1, d32.value)
+            ctx.submit_device(scene.frame(flags=abi.PT_FRAME_OUTPUT_F16), 2, d16.value)
+            for s in range(3):
+                ctx.wait(s)
+            got32 = np.empty(ref.shape, np.float32)
+            got16 = np.empty(ref.shape, np.float16)
+            assert hip.hipMemcpy(got32.ctypes.data_as(C.c_void_p), d32, got32.nbytes, 2) == 0
+            assert hip.hipMemcpy(got16.ctypes.data_as(C.c_void_p), d16, got16.nbytes, 2) == 0
+            half = half.copy()     # (the page-locked array goes away with the context)
+        want16 = ref.astype(np.float16)
+        assert np.array_equal(half.view(np.uint16), want16.view(np.uint16))
+        assert np.array_equal(got16.view(np.uint16), want16.view(np.uint16))
+        assert np.array_equal(got32.view(np.uint32), ref.view(np.uint32))
+    finally:
+        hip.hipFree(d32)
+        hip.hipFree(d16)
+
+
+def _moved(scene, k):
+    """The scene's objects with every instance shifted a little (step k): same count, so the TLAS is refitted."""
+    o = scene.objects.copy()
+    d = np.float32(0.05 * k)
+    o["local_to_world"][:, 12] += d          # translation x of the column-major matrix
+    # world_to_local = inverse: for p' = M p + (d,0,0) the inverse subtracts the shift in local space
+    for i in range(o.size):
+        l2w = o["local_to_world"][i].reshape(4, 4).T.astype(np.float64)
+        o["world_to_local"][i] = np.linalg.inv(l2w).T.reshape(16).astype(np.float32)
+    return o
+
+
+@pytest.mark.parametrize("name,n", [("instanced", 600), ("boxes", None)])
+def test_object_uploads_between_submits_leave_frames_in_flight_alone(name, n):
+    """Every frame gets its own object array, uploaded right before its submit while the earlier frames are still running;
+    each image must be the one a fresh context renders for that array (which the restatement confirms on one of them)."""
+    scene = (scenes.instanced_boxes(n_objects=n, width=320, height=200, samples=8, extent=6.0) if name == "instanced"
+             else scenes.boxes(320, 200, 32, 10))
+    steps = 6
+    arrays = [_moved(scene, k) for k in range(steps)]
+    want = []
+    for k in range(steps):
+        with abi.Context() as c:
+            c.upload_scene(scene)
+            c.upload_objects(arrays[k])
+            want.append(c.render(scene.frame(time=float(k) + 0.5)))
+    assert not np.array_equal(want[0], want[1])
+    moved = dataclasses.replace(scene, objects=arrays[2])
+    x0, y0, x1, y1 = 140, 90, 180, 110
+    ref = oracle_render(moved, moved.frame(time=2.5), rect=(x0, y0, x1, y1))
+    assert np.array_equal(want[2][y0:y1, x0:x1].view(np.uint32), ref["image"].view(np.uint32))
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        bufs = [ctx.host_array(want[0].shape, np.float32) for _ in range(3)]
+        for rep in range(2):     # the second pass runs with schedule hints and refitted trees
+            for k in range(steps + 3):
+                slot = k % 3
+                if k >= 3:
+                    ctx.wait(slot)
+                    assert np.array_equal(bufs[slot].view(np.uint32), want[k - 3].view(np.uint32)), f"pass {rep}, frame {k - 3}"
+                if k < steps:
+                    ctx.upload_objects(arrays[k])
+                    ctx.submit(scene.frame(time=float(k) + 0.5), slot, bufs[slot])
+            assert ctx.check_accel()["errors"] == 0
+
+
+def test_accumulation_follows_submit_order():
+    scene = scenes.cornell_box(64, 64, 4, 10)
+    times = [0.0, 1.5, 2.5, 3.5, 4.5]
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        want = [ctx.render(scene.frame(time=t, flags=abi.PT_FRAME_ACCUMULATE | (abi.PT_FRAME_RESET if i == 0 else 0))) for i, t in enumerate(times)]
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        bufs = [ctx.host_array(want[0].shape, np.float32) for _ in times]
+        for i, t in enumerate(times):
+            ctx.submit(scene.frame(time=t, flags=abi.PT_FRAME_ACCUMULATE | (abi.PT_FRAME_RESET if i == 0 else 0)), i, bufs[i])
+        for i in reversed(range(len(times))):
+            ctx.wait(i)
+        for i in range(len(times)):
+            assert np.array_equal(bufs[i].view(np.uint32), want[i].view(np.uint32)), f"frame {i}"
+
+
+def test_submit_and_wait_error_codes():
+    scene = scenes.cornell_box(32, 32, 1, 2)
+    with abi.Context() as ctx:
+        buf = ctx.host_array((32, 32, 4), np.float32)
+        with pytest.raises(abi.PtError) as e:
+            ctx.submit(scene.frame(), 0, buf)               # no scene yet
+        assert e.value.code == abi.PT_ERR_NOT_READY
+        ctx.upload_scene(scene)
+        with pytest.raises(abi.PtError) as e:
+            ctx.wait(0)                                      # (the failed submit left nothing behind)
+        assert e.value.code == abi.PT_ERR_NOT_READY
+        with pytest.raises(abi.PtError) as e:
+            ctx.submit(scene.frame(), abi.PT_MAX_FRAME_SLOTS, buf)
+        assert e.value.code == abi.PT_ERR_INVALID_ARGUMENT
+        with pytest.raises(abi.PtError) as e:
+            ctx.wait(abi.PT_MAX_FRAME_SLOTS)
+        assert e.value.code == abi.PT_ERR_INVALID_ARGUMENT
+        ctx.submit(scene.frame(), 0, buf)
+        with pytest.raises(abi.PtError) as e:
+            ctx.submit(scene.frame(), 0, buf)               # the slot is taken
+        assert e.value.code == abi.PT_ERR_INVALID_ARGUMENT and "pt_render_wait" in e.value.message
+        ctx.wait(0)
+        with pytest.raises(abi.PtError) as e:
+            ctx.wait(0)
+        assert e.value.code == abi.PT_ERR_NOT_READY
+        ref = ctx.render(scene.frame())
+        assert np.array_equal(buf.view(np.uint32), ref.view(np.uint32))
+        # a context destroyed with frames in flight waits for them
+        ctx.submit(scene.frame(samples=64, bounces=10), 1, buf)
+        ctx.submit(scene.frame(samples=64, bounces=10), 2, buf)
+
+
+def test_frames_in_flight_at_1080p_equal_one_at_a_time():
+    """The headline configuration's size: three slots taking frames in turn, hints and split chunks active from each
+    slot's second frame on; every image must be the one the synchronous call gives."""
+    scene = scenes.scene_glb_textured(1920, 1080, 16, 10)
+    times = [0.5, 1.5, 2.5]
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        want = [ctx.render(scene.frame(time=t)) for t in times]
+        bufs = [ctx.host_array(want[0].shape, np.float32) for _ in range(3)]
+        for rep in range(3):
+            for s, t in enumerate(times):
+                ctx.submit(scene.frame(time=t), s, bufs[s])
+            for s in range(3):
+                ctx.wait(s)
+                assert np.array_equal(bufs[s].view(np.uint32), want[s].view(np.uint32)), f"pass {rep}, slot {s}"
+                assert ctx.stats()["rays"] > 0

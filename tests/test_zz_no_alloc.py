@@ -23,6 +23,9 @@ class Hip:
         self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         self.lib.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        self.lib.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.lib.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.lib.hipStreamDestroy.argtypes = [C.c_void_p]
 
     def check(self, rc, what):
         assert rc == 0, f"{what} failed with HIP error {rc}"
@@ -114,4 +117,45 @@ def test_noalloc_limits_are_reported():
                 ctx.render_device_noalloc(scene.frame(), d_out.value)
             assert e.value.code == abi.PT_ERR_NOT_READY
     finally:
+        hip.free(d_out)
+
+
+def test_scene_changes_and_destroy_right_after_an_asynchronous_noalloc_frame():
+    """On a caller's stream the call returns while the frame is still running. An upload that follows at once must not
+    change what that frame reads, and destroying the context must wait for it."""
+    a = scenes.instanced_boxes(n_objects=600, width=256, height=160, samples=16, extent=6.0)
+    b = scenes.instanced_boxes(n_objects=600, width=256, height=160, samples=16, extent=6.0, seed=77)
+    hip = Hip()
+    stream = C.c_void_p()
+    hip.check(hip.lib.hipStreamCreate(C.byref(stream)), "hipStreamCreate")
+    f = a.frame()
+    n = f.width * f.height
+    d_ref, d_out = hip.malloc(16 * n), hip.malloc(16 * n)
+    try:
+        with abi.Context() as ctx:
+            ctx.upload_scene(a)
+            ctx.render_device(f, d_ref.value)
+            want_a = hip.to_host(d_ref, (f.height, f.width, 4), np.float32)
+            ctx.upload_objects(b.objects)
+            ctx.render_device(f, d_ref.value)
+            want_b = hip.to_host(d_ref, (f.height, f.width, 4), np.float32)
+            assert not np.array_equal(want_a, want_b)
+            ctx.upload_objects(a.objects)
+            for k in range(3):
+                hip.fill(d_out, 0xFF, 16 * n)
+                ctx.render_device_noalloc(f, d_out.value, stream.value)     # returns at once
+                ctx.upload_objects(b.objects if k % 2 == 0 else a.objects)  # ... and the scene changes under it
+                hip.check(hip.lib.hipStreamSynchronize(stream), "hipStreamSynchronize")
+                got = hip.to_host(d_out, (f.height, f.width, 4), np.float32)
+                want = want_a if k % 2 == 0 else want_b
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"call {k}"
+            ctx.upload_meshes(a.meshes, a.indices, a.vertices)              # waits for everything, rebuilds in place
+            ctx.render_device_noalloc(f, d_out.value, stream.value)
+        # (the context is gone: pt_destroy waited for the frame)
+        got = hip.to_host(d_out, (f.height, f.width, 4), np.float32)
+        assert np.array_equal(got.view(np.uint32), want_b.view(np.uint32))
+    finally:
+        hip.check(hip.lib.hipStreamSynchronize(stream), "hipStreamSynchronize")
+        hip.lib.hipStreamDestroy(stream)
+        hip.free(d_ref)
         hip.free(d_out)

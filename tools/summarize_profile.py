@@ -145,6 +145,8 @@ def main():
         tf = dst / "traffic.json"
         cur = json.loads(tf.read_text()) if tf.exists() else {}
         cur[args.workload] = {"hbm_bytes_per_launch": hbm["hbm_bytes_per_launch"], "tag": args.tag}
+        if "avg_kernel_ms" in out:   # the kernel's average duration in the one-frame-at-a-time trace (bench.py: roofline.kernel_ms_rocprof)
+            cur[args.workload]["k_paths_ms_rocprof"] = round(out["avg_kernel_ms"], 4)
         for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES",
                   "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32",
                   "SQ_INST_CYCLES_VALU", "SQ_WAIT_INST_LDS", "SQ_BUSY_CYCLES"):
