@@ -53,7 +53,10 @@ with abi.Context() as ctx:
         ctx.render_device(big.frame(time=t), o.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         torch.cuda.synchronize(dev)
         want.append(o.cpu().numpy())
+import os
+os.environ["PT_AMD_DEBUG"] = "1"     # (read when a context is created: these contexts print a line per frame on stderr)
 ctxs = [abi.Context() for _ in range(3)]
+del os.environ["PT_AMD_DEBUG"]
 streams = [torch.cuda.Stream(dev) for _ in range(3)]
 outs = [[torch.zeros((1080, 1920, 4), dtype=torch.float32, device=dev) for _ in times] for _ in range(3)]
 for c in ctxs:
@@ -70,11 +73,10 @@ ctxs[0].render_device(big.frame(time=0.5), outs[0][0].data_ptr(), streams[0].cud
 torch.cuda.synchronize(dev)
 import time
 time.sleep(0.05)
-import os
 r, w = os.pipe()
 saved = os.dup(2)
+sys.stderr.flush()
 os.dup2(w, 2)
-os.environ["PT_AMD_DEBUG"] = "1"
 try:
     ctxs[0].render_device(big.frame(time=0.5), outs[0][0].data_ptr(), streams[0].cuda_stream)
     torch.cuda.synchronize(dev)
@@ -82,7 +84,6 @@ try:
 finally:
     os.dup2(saved, 2)
     os.close(w)
-    del os.environ["PT_AMD_DEBUG"]
 log = os.read(r, 1 << 16).decode()
 assert "other frames running at its start 0\n" in log, log[-600:]
 assert np.array_equal(outs[0][0].cpu().numpy().view(np.uint32), want[0].view(np.uint32))
