@@ -210,6 +210,7 @@ struct pt_ctx {
     uint32_t split_load_8ths = 16;                 // chunks are handed out in parts only while work / longest chunk <= this/8 x the waves of the launch; 0: always
     uint32_t group_margin_8ths[2] = {24, 8};       // see ChunkOrderInfo::n_groups: waves = this/8 x work / longest chunk, {frame alone on the device, other frames running}; 0: always the whole grid
     bool blas_sah = true;         // BLAS of moderate meshes by the surface-area heuristic on the host (else Morton order)
+    bool tlas_sah = true;         // the TLAS of a newly arrived object set likewise (PT_AMD_TLAS_BUILDER=lbvh: always Morton order)
     bool strict_hints = false;    // see render_enqueue
     uint64_t scene_version = 0;   // bumped by every upload
     uint32_t acc_w = 0, acc_h = 0, acc_frames = 0;
@@ -287,8 +288,10 @@ int build_lbvh(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t
 // middle). Produces exactly what build_lbvh() leaves behind for a BLAS: the nodes (root = node 0, leaves referenced by
 // sorted position), the sorted order in t_vals0, the range of positions below every node in t_ranges, the depth in
 // info_slot[0]. The boxes are unions of the very boxes the device computed for the triangles.
+// With leaf_is_pos == false (a TLAS: leaves name the primitive itself) it also leaves the parent links a refit climbs
+// (t_par_int, t_par_leaf, in k_karras's form) and the per-node ranges are not kept.
 int build_sah_host(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint32_t first, uint32_t n, BvhNode* nodes,
-                   uint32_t node_base, uint32_t* info_slot) {
+                   uint32_t node_base, uint32_t* info_slot, bool leaf_is_pos = true) {
     hipStream_t s = ctx->stream;
     std::vector<float4> lo(n), hi(n);
     PT_HIP(ctx, hipMemcpyAsync(lo.data(), box_lo + first, sizeof(float4) * n, hipMemcpyDeviceToHost, s));
@@ -315,6 +318,8 @@ int build_sah_host(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint
     }
     std::vector<BvhNode> out(n - 1);
     std::vector<uint2> ranges(n - 1);
+    std::vector<uint32_t> par_int, par_leaf;
+    if (!leaf_is_pos) { par_int.assign(n, 0u); par_leaf.assign(n, 0u); }
     struct Task { uint32_t node, lo, hi; };
     std::vector<Task> stack;
     stack.push_back({0u, 0u, n - 1u});
@@ -380,11 +385,14 @@ int build_sah_host(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint
             Box bx = empty();
             for (uint32_t k = a; k <= b; ++k) grow(bx, order[k]);
             uint32_t ref;
+            const uint32_t link = t.node | (side ? 0x80000000u : 0u);   // parent link: bit 31 = "I am the right child"
             if (a == b) {
-                ref = PT_LEAF_BIT | a;
+                ref = PT_LEAF_BIT | (leaf_is_pos ? a : order[a]);
+                if (!leaf_is_pos) par_leaf[a] = link;
             } else {
                 const uint32_t child = next_node++;
                 ref = node_base + child;
+                if (!leaf_is_pos) par_int[child] = link;
                 stack.push_back({child, a, b});
             }
             uint32_t bits = ref;
@@ -409,6 +417,12 @@ int build_sah_host(pt_ctx* ctx, const float4* box_lo, const float4* box_hi, uint
     PT_HIP(ctx, ctx->t_ranges.ensure(sizeof(uint2) * n));
     PT_HIP(ctx, hipMemcpyAsync(ctx->t_vals0.p, order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
     PT_HIP(ctx, hipMemcpyAsync(ctx->t_ranges.p, ranges.data(), sizeof(uint2) * (n - 1), hipMemcpyHostToDevice, s));
+    if (!leaf_is_pos) {
+        PT_HIP(ctx, ctx->t_par_int.ensure(sizeof(uint32_t) * n));
+        PT_HIP(ctx, ctx->t_par_leaf.ensure(sizeof(uint32_t) * n));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->t_par_int.p, par_int.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->t_par_leaf.p, par_leaf.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+    }
     PT_HIP(ctx, hipMemcpyAsync(nodes, out.data(), sizeof(BvhNode) * (n - 1), hipMemcpyHostToDevice, s));
     PT_HIP(ctx, hipMemcpyAsync(info_slot, &depth[0], sizeof(uint32_t), hipMemcpyHostToDevice, s));
     PT_HIP(ctx, hipStreamSynchronize(s));   // (the host vectors go out of scope)
@@ -494,6 +508,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         }
         if (const char* e = std::getenv("PT_AMD_CARRY_ACQUIRE")) ctx->carry_acquire = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_BLAS_BUILDER")) ctx->blas_sah = std::strcmp(e, "lbvh") != 0;
+        if (const char* e = std::getenv("PT_AMD_TLAS_BUILDER")) ctx->tlas_sah = std::strcmp(e, "lbvh") != 0;
         if (const char* e = std::getenv("PT_AMD_STRICT_HINTS")) ctx->strict_hints = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_WALK_QUOTA")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->walk_quota = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_BLAS_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= (int)PT_WIDE_MAX_LEAF) ctx->blas_max_leaf = (uint32_t)v; }
@@ -965,7 +980,12 @@ int rebuild_objects(pt_ctx* ctx, uint32_t target) {
                 refitted = true;
             } else {
                 PT_HIP(ctx, ctx->d_tlas_bnodes.ensure(sizeof(BvhNode) * (size_t)(n - 1)));
-                int rc = build_lbvh(ctx, T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false);
+                // A scene that arrives (first upload, or another number of objects) gets the surface-area tree from the host when
+                // it is of moderate size: it is walked by every ray of every frame until the objects change, and refits keep its
+                // topology. The periodic fresh build of a scene whose objects keep moving uses the fast device builder.
+                const bool sah = ctx->tlas_sah && n <= kSahHostMaxTris && (ctx->tlas_built_n != n);
+                int rc = sah ? build_sah_host(ctx, T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false)
+                             : build_lbvh(ctx, T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false);
                 if (rc != PT_OK) return rc;
                 PT_HIP(ctx, ctx->d_tlas_order.ensure(nb));
                 PT_HIP(ctx, ctx->d_tlas_par_int.ensure(nb));
