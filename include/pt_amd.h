@@ -300,9 +300,12 @@ int pt_host_free(pt_ctx* ctx, void* ptr);
 /* ---- several GPUs behind one handle ------------------------------------------ */
 /* No counterpart in the reference (one wgpu device, src/shader.rs:121-213). One
  * process drives every listed GPU: the scene is replicated (uploads go to all of
- * them), a frame is partitioned, and the one exchange step is a sum of the f32
- * images onto the first listed GPU with RCCL (ncclReduce, all GPUs in one group
- * call); librccl is opened at pt_multi_create, it is not a link dependency.
+ * them at once, one host thread per GPU inside the call), a frame is partitioned,
+ * and the one exchange step brings the f32 images to the first listed GPU with
+ * RCCL (ncclSend from every other GPU, ncclRecv on the first, one group call: on
+ * xGMI each GPU has its own link to the first one), where they are added in list
+ * order, image 0 + image 1 + ..., so the result is reproducible bit for bit for any
+ * number of GPUs. librccl is opened at pt_multi_create, it is not a link dependency.
  * With one device the calls are exactly their single-GPU counterparts. */
 #define PT_MULTI_MAX_DEVICES 16
 enum {
@@ -310,13 +313,14 @@ enum {
                                     the sum of the disjoint images is bit-identical to one GPU's frame       */
     PT_MULTI_VIRTUAL_FRAMES = 1  /* GPU k renders the whole frame with time + k + 0.5 (k > 0): other seeds, as
                                     successive frames of the reference have (src/raytrace.wgsl:210); the result is
-                                    sum * (1/N), N x samples per pixel per call                                 */
+                                    (((f0 + f1) + f2) + ...) * (1/N) in f32, N x samples per pixel per call     */
 };
 /* PtMultiConfig.flags */
 #define PT_MULTI_FLAG_HOST_SUM 0x1u /* diagnostic: sum the images on the host, in list order, instead of with RCCL;
                                        a device may then be listed more than once (rehearsal on a one-GPU machine) */
 #define PT_MULTI_FLAG_FORCE_COLLECTIVE 0x2u /* diagnostic: a one-device handle also goes through RCCL (a communicator of
-                                               one rank, the same ncclReduce call), instead of being plain pt_render */
+                                               one rank that sends its image to itself with the same ncclSend / ncclRecv
+                                               calls), instead of being plain pt_render */
 typedef struct PtMultiConfig {
     uint32_t abi_version; /* PT_ABI_VERSION */
     uint32_t n_devices;   /* 1..PT_MULTI_MAX_DEVICES */

@@ -52,6 +52,18 @@
 
 #include "../include/pt_amd.h"
 
+/* Alternative evaluations, built as separate libraries (oracle/Makefile) only to measure how far other legal evaluations
+ * of the same WGSL are from the one the kernels implement:
+ *   -DPTO_IEEE_NORMALIZE  normalize(v) = v * (1 / sqrt(dot(v,v))), both correctly rounded
+ *   -DPTO_NO_FMA          no fused multiply-add anywhere: every fma(a,b,c) below is a*b rounded, then + c rounded
+ *                         (what a software rasteriser without FMA contraction computes)
+ *   -DPTO_LIBM_TRIG       sin/cos from the C library instead of the fixed polynomials */
+#ifdef PTO_NO_FMA
+#define PTO_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define PTO_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
+
 /* reference src/math.wgsl:3-6 */
 #define EPSILON 4.88e-4f
 #define WGSL_INFINITY 10000000.0f
@@ -88,9 +100,9 @@ typedef struct {
 
 /* ---- vector helpers (the numerical policy above) -------------------------- */
 static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
-static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline float dot3(v3 a, v3 b) { return PTO_FMA(a.z, b.z, PTO_FMA(a.y, b.y, a.x * b.x)); }
 static inline v3 cross3(v3 a, v3 b) {
-    return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+    return V3(PTO_FMA(a.y, b.z, -(a.z * b.y)), PTO_FMA(a.z, b.x, -(a.x * b.z)), PTO_FMA(a.x, b.y, -(a.y * b.x)));
 }
 static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 add3(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -98,7 +110,7 @@ static inline v3 mul3(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); 
 static inline v3 scale3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
 static inline v3 madd3(v3 a, v3 b, float s) { /* a + b*s */
-    return V3(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z));
+    return V3(PTO_FMA(b.x, s, a.x), PTO_FMA(b.y, s, a.y), PTO_FMA(b.z, s, a.z));
 }
 /* inverseSqrt by a fixed recipe (see the numerical policy above) */
 static inline float rsqrt_fixed(float d) {
@@ -107,9 +119,9 @@ static inline float rsqrt_fixed(float d) {
     c.u = 0x5f375a86u - (c.u >> 1);
     float y = c.f;
     const float hd = 0.5f * d;
-    y = y * fmaf(-(hd * y), y, 1.5f);
-    y = y * fmaf(-(hd * y), y, 1.5f);
-    y = y * fmaf(-(hd * y), y, 1.5f);
+    y = y * PTO_FMA(-(hd * y), y, 1.5f);
+    y = y * PTO_FMA(-(hd * y), y, 1.5f);
+    y = y * PTO_FMA(-(hd * y), y, 1.5f);
     return y;
 }
 float pto_rsqrt(float d) { return rsqrt_fixed(d); }
@@ -122,9 +134,9 @@ static inline v3 normalize3(v3 a) {
     return V3(a.x * r, a.y * r, a.z * r);
 }
 static inline v3 xform_dir(const float* m, v3 v) {
-    return V3(fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)),
-              fmaf(m[9], v.z, fmaf(m[5], v.y, m[1] * v.x)),
-              fmaf(m[10], v.z, fmaf(m[6], v.y, m[2] * v.x)));
+    return V3(PTO_FMA(m[8], v.z, PTO_FMA(m[4], v.y, m[0] * v.x)),
+              PTO_FMA(m[9], v.z, PTO_FMA(m[5], v.y, m[1] * v.x)),
+              PTO_FMA(m[10], v.z, PTO_FMA(m[6], v.y, m[2] * v.x)));
 }
 static inline v3 xform_point(const float* m, v3 v) {
     v3 r = xform_dir(m, v);
@@ -141,13 +153,13 @@ static inline uint32_t f2u(float f) {
 void pto_sincos(float x, float* s_out, float* c_out) {
     float kf = rintf(x * 0.636619772367581343f);
     int k = (fabsf(kf) < 1073741824.0f) ? (int)kf : 0;
-    float y = fmaf(-kf, 1.57079637050628662109375f, x);
-    y = fmaf(-kf, -4.37113900018624283e-8f, y);
+    float y = PTO_FMA(-kf, 1.57079637050628662109375f, x);
+    y = PTO_FMA(-kf, -4.37113900018624283e-8f, y);
     float z = y * y;
-    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
-    float s = fmaf(ps * z, y, y);
-    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-    float c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    float ps = PTO_FMA(PTO_FMA(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float s = PTO_FMA(ps * z, y, y);
+    float pc = PTO_FMA(PTO_FMA(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float c = PTO_FMA(pc * z, z, PTO_FMA(-0.5f, z, 1.0f));
     switch (k & 3) {
         case 0: *s_out = s;  *c_out = c;  break;
         case 1: *s_out = c;  *c_out = -s; break;
@@ -191,7 +203,12 @@ static inline v3 cosine_sample(Invocation* iv) {
     float sin_theta = sqrtf(sqr_sin_theta);
     float cos_theta = sqrtf(1.0f - sqr_sin_theta);
     float s, c;
+#ifdef PTO_LIBM_TRIG
+    s = sinf(phi);
+    c = cosf(phi);
+#else
     pto_sincos(phi, &s, &c);
+#endif
     return V3(sin_theta * c, sin_theta * s, cos_theta);
 }
 
@@ -273,11 +290,11 @@ static int hit_mesh(Invocation* iv, uint32_t object_index, float t_min, v3 rpos,
         v3 na = V3(va->normal[0], va->normal[1], va->normal[2]);
         v3 nb = V3(vb->normal[0], vb->normal[1], vb->normal[2]);
         v3 nc = V3(vc->normal[0], vc->normal[1], vc->normal[2]);
-        v3 _n = V3(fmaf(nc.x, v, fmaf(nb.x, u, na.x * w)),
-                   fmaf(nc.y, v, fmaf(nb.y, u, na.y * w)),
-                   fmaf(nc.z, v, fmaf(nb.z, u, na.z * w)));
-        float uvx = fmaf(vc->uv[0], v, fmaf(vb->uv[0], u, va->uv[0] * w));
-        float uvy = fmaf(vc->uv[1], v, fmaf(vb->uv[1], u, va->uv[1] * w));
+        v3 _n = V3(PTO_FMA(nc.x, v, PTO_FMA(nb.x, u, na.x * w)),
+                   PTO_FMA(nc.y, v, PTO_FMA(nb.y, u, na.y * w)),
+                   PTO_FMA(nc.z, v, PTO_FMA(nb.z, u, na.z * w)));
+        float uvx = PTO_FMA(vc->uv[0], v, PTO_FMA(vb->uv[0], u, va->uv[0] * w));
+        float uvy = PTO_FMA(vc->uv[1], v, PTO_FMA(vb->uv[1], u, va->uv[1] * w));
 
         iv->hit_record.t = t;
         iv->hit_record.p = xform_point(object->local_to_world, _p);
@@ -325,7 +342,7 @@ static v3 sample_texture(const PtoScene* sc, uint32_t idx, float u, float v) {
 static inline float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 static inline float pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
 /* bevy_pbr::lighting::F_Schlick with f0 = 1: f0 + (f90 - f0) * pow(1 - u, 5) */
-static inline float f_schlick_1(float f90, float u) { return fmaf(f90 - 1.0f, pow5(1.0f - u), 1.0f); }
+static inline float f_schlick_1(float f90, float u) { return PTO_FMA(f90 - 1.0f, pow5(1.0f - u), 1.0f); }
 
 static void calculate_brdf(Invocation* iv, v3 ray_dir, const PtMaterial* material, v3* out_dir, v3* out_color) {
     const PtoScene* sc = iv->sc;
@@ -335,9 +352,9 @@ static void calculate_brdf(Invocation* iv, v3 ray_dir, const PtMaterial* materia
     hugues_moller(N, &tt, &bb);
     v3 cs = cosine_sample(iv);
     /* mat3x3(t,b,n) * cs = t*cs.x + b*cs.y + n*cs.z */
-    v3 lam = V3(fmaf(N.x, cs.z, fmaf(bb.x, cs.y, tt.x * cs.x)),
-                fmaf(N.y, cs.z, fmaf(bb.y, cs.y, tt.y * cs.x)),
-                fmaf(N.z, cs.z, fmaf(bb.z, cs.y, tt.z * cs.x)));
+    v3 lam = V3(PTO_FMA(N.x, cs.z, PTO_FMA(bb.x, cs.y, tt.x * cs.x)),
+                PTO_FMA(N.y, cs.z, PTO_FMA(bb.y, cs.y, tt.y * cs.x)),
+                PTO_FMA(N.z, cs.z, PTO_FMA(bb.z, cs.y, tt.z * cs.x)));
     v3 lambertian_ray = normalize3(lam);
     /* :159 reflect(I,N) = I - 2*dot(N,I)*N */
     float k2 = 2.0f * dot3(N, ray_dir);
@@ -345,9 +362,9 @@ static void calculate_brdf(Invocation* iv, v3 ray_dir, const PtMaterial* materia
     /* :160 mix(a,b,t) = a*(1-t) + b*t */
     float rough_in = material->roughness;
     float om = 1.0f - rough_in;
-    v3 new_ray_dir = V3(fmaf(lambertian_ray.x, rough_in, reflection_ray.x * om),
-                        fmaf(lambertian_ray.y, rough_in, reflection_ray.y * om),
-                        fmaf(lambertian_ray.z, rough_in, reflection_ray.z * om));
+    v3 new_ray_dir = V3(PTO_FMA(lambertian_ray.x, rough_in, reflection_ray.x * om),
+                        PTO_FMA(lambertian_ray.y, rough_in, reflection_ray.y * om),
+                        PTO_FMA(lambertian_ray.z, rough_in, reflection_ray.z * om));
 
     /* :162-170 */
     v3 albedo = V3(material->albedo[0], material->albedo[1], material->albedo[2]);
@@ -370,7 +387,7 @@ static void calculate_brdf(Invocation* iv, v3 ray_dir, const PtMaterial* materia
     float LdotH = saturate(dot3(L, H));
 
     /* :199 Fd_Burley */
-    float f90 = fmaf((2.0f * roughness) * LdotH, LdotH, 0.5f);
+    float f90 = PTO_FMA((2.0f * roughness) * LdotH, LdotH, 0.5f);
     float light_scatter = f_schlick_1(f90, NdotL);
     float view_scatter = f_schlick_1(f90, NdotV);
     float fd = (light_scatter * view_scatter) * (1.0f / PI_F);
@@ -416,9 +433,9 @@ static void fragment(const PtoScene* sc, const PtFrame* fr, const uint32_t* tri_
     const float* wfv = fr->world_from_view;
     const float* vfc = fr->view_from_clip;
     v3 initial_origin = V3(wfv[12], wfv[13], wfv[14]);
-    v3 temp = V3(fmaf(vfc[4], dy, vfc[0] * dx) + vfc[8] + vfc[12],
-                 fmaf(vfc[5], dy, vfc[1] * dx) + vfc[9] + vfc[13],
-                 fmaf(vfc[6], dy, vfc[2] * dx) + vfc[10] + vfc[14]);
+    v3 temp = V3(PTO_FMA(vfc[4], dy, vfc[0] * dx) + vfc[8] + vfc[12],
+                 PTO_FMA(vfc[5], dy, vfc[1] * dx) + vfc[9] + vfc[13],
+                 PTO_FMA(vfc[6], dy, vfc[2] * dx) + vfc[10] + vfc[14]);
     v3 initial_direction = xform_dir(wfv, normalize3(temp));
 
     uint32_t bounces = fr->settings.bounces, samples = fr->settings.samples;
@@ -451,8 +468,8 @@ static void fragment(const PtoScene* sc, const PtFrame* fr, const uint32_t* tri_
                 v3 emissive = V3(material->emissive[0], material->emissive[1], material->emissive[2]);
                 if (material->emissive_texture != U32_MAX)
                     emissive = sample_texture(sc, material->emissive_texture, iv.hit_record.u, iv.hit_record.v);
-                color = V3(fmaf(ray_color.x, emissive.x, color.x), fmaf(ray_color.y, emissive.y, color.y),
-                           fmaf(ray_color.z, emissive.z, color.z));
+                color = V3(PTO_FMA(ray_color.x, emissive.x, color.x), PTO_FMA(ray_color.y, emissive.y, color.y),
+                           PTO_FMA(ray_color.z, emissive.z, color.z));
                 v3 alb = V3(material->albedo[0], material->albedo[1], material->albedo[2]);
                 if (dot3(alb, alb) < EPSILON) break;
 
@@ -468,8 +485,8 @@ static void fragment(const PtoScene* sc, const PtFrame* fr, const uint32_t* tri_
                 rpos = madd3(iv.hit_record.p, rdir, 0.001f);
                 ray_color = mul3(ray_color, bcol);
             } else {
-                color = V3(fmaf(ray_color.x, sky.x, color.x), fmaf(ray_color.y, sky.y, color.y),
-                           fmaf(ray_color.z, sky.z, color.z));
+                color = V3(PTO_FMA(ray_color.x, sky.x, color.x), PTO_FMA(ray_color.y, sky.y, color.y),
+                           PTO_FMA(ray_color.z, sky.z, color.z));
                 break;
             }
             /* :266-269 */

@@ -34,8 +34,11 @@ class PtoAux(C.Structure):
                 ("primary_t", C.c_void_p), ("ray_count", C.c_void_p)]
 
 
-_lib = None
-_lib_ieee = None
+# variant -> library: "recipe" is the evaluation the kernels implement; the others are further legal evaluations of the same
+# WGSL (see the build flags in oracle/pt_oracle.c), kept only to measure distances
+VARIANTS = {"recipe": ORACLE_SO, "ieee": ORACLE_IEEE_SO, "nofma": ORACLE_DIR / "libpt_oracle_nofma.so",
+            "nofma_libm": ORACLE_DIR / "libpt_oracle_nofma_libm.so"}
+_libs = {}
 
 
 def build_oracle():
@@ -43,20 +46,14 @@ def build_oracle():
 
 
 def load_oracle(variant="recipe"):
-    """variant "recipe": the evaluation the kernels implement; "ieee": normalize() with sqrt and division."""
-    global _lib, _lib_ieee
-    if variant == "ieee":
-        if _lib_ieee is None:
-            if not ORACLE_IEEE_SO.exists():
-                build_oracle()
-            _lib_ieee = _declare(C.CDLL(str(ORACLE_IEEE_SO)))
-        return _lib_ieee
-    if _lib is not None:
-        return _lib
-    if not ORACLE_SO.exists():
-        build_oracle()
-    _lib = _declare(C.CDLL(str(ORACLE_SO)))
-    return _lib
+    """variant "recipe": the evaluation the kernels implement; "ieee": normalize() with sqrt and division; "nofma": that and
+    no fused multiply-add anywhere; "nofma_libm": that and the C library's sin/cos."""
+    if variant not in _libs:
+        so = VARIANTS[variant]
+        if not so.exists():
+            build_oracle()
+        _libs[variant] = _declare(C.CDLL(str(so)))
+    return _libs[variant]
 
 
 def _declare(lib):

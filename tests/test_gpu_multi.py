@@ -2,7 +2,8 @@
 one listed device equals the single-GPU entry points bit for bit; RCCL can be opened and has the entry points the
 library uses; and, with the host-side sum that allows one GPU to be listed twice or three times, the two partitions:
 tiles assemble to the single-GPU frame bit for bit, virtual frames are the mean of the per-GPU frames as the CPU
-restatement defines it. The ncclReduce itself runs only on a machine with several GPUs."""
+restatement defines it; and the RCCL leg with a communicator of one rank that sends its image to itself. A transfer
+between two different GPUs runs only on a machine that has them."""
 import numpy as np
 import pytest
 
@@ -35,8 +36,8 @@ def test_rccl_can_be_opened():
 
 @pytest.mark.parametrize("mode", [abi.PT_MULTI_TILES, abi.PT_MULTI_VIRTUAL_FRAMES])
 def test_one_rank_through_the_collective(mode):
-    """The RCCL leg itself on the one GPU there is: a communicator of one rank, the grouped ncclReduce onto rank 0 behind
-    the frame on its stream, the scale and the copy. The image must be pt_render's, twice in a row."""
+    """The RCCL leg itself on the one GPU there is: a communicator of one rank, the grouped ncclSend / ncclRecv (to itself)
+    behind the frame on its stream, the summing kernel and the copy. The image must be pt_render's, twice in a row."""
     scene = scenes.cornell_box(100, 61, 4, 10)
     frame = scene.frame(time=0.5)
     with abi.Context() as ctx:

@@ -230,33 +230,27 @@ def test_fixed_recipe_inverse_sqrt_accuracy():
     assert np.array_equal(y.view(np.uint32), got.view(np.uint32))
 
 
-def test_normalize_recipe_against_the_correctly_rounded_evaluation(tmp_path):
-    """How much the choice of normalize() evaluation matters: the restatement built with sqrt and division
-    (-DPTO_IEEE_NORMALIZE) gives the same primary hits; nearly every pixel runs the same paths and agrees to rounding
-    noise; the few pixels in which one accept/reject decision flips desynchronise their RNG stream and differ at noise
-    level (the sensitivity any two drivers running the reference have)."""
-    import subprocess
-    from pathlib import Path
-    import tests.oracle_lib as ol
+@pytest.mark.parametrize("variant", ["ieee", "nofma", "nofma_libm"])
+def test_other_legal_evaluations_of_the_same_wgsl(variant):
+    """How much the choice of evaluation matters (oracle/Makefile builds the variants: normalize() with sqrt and division;
+    that and no fused multiply-add anywhere; that and the C library's sin/cos): every variant gives the same primary hits as
+    the evaluation the kernels implement; nearly every pixel runs the same paths and agrees to rounding noise; the few pixels
+    in which one accept/reject decision flips desynchronise their RNG stream and differ at noise level (the sensitivity any
+    two drivers running the reference have). On the Cornell box at its stated 512 x 512 and 16 samples that handful of
+    pixels alone puts the whole image 5e-3 to 7e-3 apart in relative RMSE."""
     from path_tracing_amd import scenes
-    root = Path(__file__).resolve().parent.parent
-    alt = tmp_path / "libpt_oracle_ieee.so"
-    subprocess.run(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-mavx2", "-fopenmp", "-fPIC", "-shared",
-                    "-DPTO_IEEE_NORMALIZE", f"-I{root / 'include'}", "-o", str(alt), str(root / "oracle" / "pt_oracle.c"), "-lm"], check=True)
-    results = {}
-    saved = (ol._lib, ol.ORACLE_SO)
-    try:
-        for tag, so in (("recipe", saved[1]), ("ieee", alt)):
-            ol._lib, ol.ORACLE_SO = None, Path(so)
-            for name, sc in (("cornell", scenes.cornell_box(96, 96, 8, 10)), ("boxes", scenes.boxes(160, 90, 16, 10))):
-                results[tag, name] = ol.oracle_render(sc, sc.frame())
-    finally:
-        ol._lib, ol.ORACLE_SO = None, saved[1]
-    for name in ("cornell", "boxes"):
-        a, b = results["recipe", name], results["ieee", name]
-        assert np.array_equal(a["primary_flat_id"], b["primary_flat_id"])
+    from tests.oracle_lib import oracle_render
+    for name, sc, whole in (("cornell", scenes.cornell_box(512, 512, 16, 10), 2e-2), ("boxes", scenes.boxes(160, 90, 64, 10), 1e-3)):
+        a, b = oracle_render(sc, sc.frame()), oracle_render(sc, sc.frame(), variant=variant)
+        assert np.array_equal(a["primary_object"], b["primary_object"]), name
+        assert np.array_equal(a["primary_flat_id"], b["primary_flat_id"]), name
+        assert np.allclose(a["primary_t"], b["primary_t"], rtol=1e-6, atol=0.0), name
         x, y = a["image"][..., :3].astype(np.float64), b["image"][..., :3].astype(np.float64)
         same_paths = a["ray_count"] == b["ray_count"]
-        assert same_paths.mean() >= 0.995
+        assert same_paths.mean() >= 0.9995, name
         rel = np.abs(x - y).max(axis=-1) / np.maximum(np.abs(y).max(axis=-1), 1e-6)
-        assert (rel <= 1e-5).mean() >= 0.995     # rounding noise only, in all but a handful of pixels
+        assert (rel <= 1e-5).mean() >= 0.9995, name     # rounding noise only, in all but a handful of pixels
+        d = float(np.sqrt(((x - y) ** 2).sum() / (y ** 2).sum()))
+        d_same = float(np.sqrt(((x[same_paths] - y[same_paths]) ** 2).sum() / (y[same_paths] ** 2).sum()))
+        print(f"{name} vs {variant}: rRMSE {d:.3e} (pixels with the same paths: {d_same:.3e}, {same_paths.mean():.6f} of all)")
+        assert d <= whole and d_same <= 1e-6, name
