@@ -25,6 +25,7 @@ namespace {
 constexpr uint32_t kBlasMinTris = 16;   // PT_ACCEL_AUTO: meshes with more triangles than this get a BLAS
 constexpr uint32_t kTlasMinObjects = 12; // PT_ACCEL_AUTO: scenes with more objects than this get a TLAS
 constexpr uint32_t kMaxStackDepth = 96;
+constexpr uint32_t kBlasNeedMaxSah = 48;    // stack entries a surface-area BLAS may need before the mesh is built in Morton order instead
 constexpr uint32_t kSahHostMaxTris = 1u << 17;     // meshes up to this many triangles get their BLAS from the host-side builder
 constexpr uint32_t kCollapseOneGroupMax = 4096;   // primitives up to which one workgroup makes the whole wide tree
 constexpr uint32_t kTlasMaxRefits = 15;  // object uploads that may refit the TLAS before it is built afresh  // LDS: 4 waves * depth * 256 B per workgroup
@@ -703,29 +704,54 @@ int pt_upload_meshes(pt_ctx* ctx, const PtMesh* meshes, uint32_t n_meshes, const
             PT_HIP(ctx, hipGetLastError());
         }
         PT_HIP(ctx, hipMemsetAsync(ctx->t_info.p, 0, sizeof(uint32_t) * 8 * (size_t)(n_meshes + 1), s));
-        for (uint32_t m = 0; m < n_meshes; ++m) {
-            if (node_base[m] == PT_NONE) continue;
+        // One mesh's BLAS: binary tree (surface-area builder on the host for moderate meshes, Morton order on the device
+        // otherwise), triangle records in leaf order, 4-wide tree.
+        auto build_blas = [&](uint32_t m, bool sah) -> int {
             const uint32_t first = hm[m].tri_first, cnt = hm[m].tri_count;
             uint32_t* info = ctx->t_info.as<uint32_t>() + 8 * (size_t)m;
             BvhNode* bn = ctx->d_blas_bnodes.as<BvhNode>() + node_base[m];
-            // moderate meshes get the better tree from the host, very large ones the fast one from the device
-            int rc = (ctx->blas_sah && cnt <= kSahHostMaxTris)
-                         ? build_sah_host(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), first, cnt, bn, node_base[m], info)
+            int rc = sah ? build_sah_host(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), first, cnt, bn, node_base[m], info)
                          : build_lbvh(ctx, ctx->d_tri_lo.as<float4>(), ctx->d_tri_hi.as<float4>(), first, cnt, bn, node_base[m], info, true);
             if (rc != PT_OK) return rc;
-            // the mesh's triangle records in the order of the tree's leaves, and which triangle each one is
-            PT_HIP(ctx, ctx->t_tris_tmp.ensure(sizeof(DTri) * (size_t)cnt));
-            k_permute_tris<<<div_up(cnt, 256), 256, 0, s>>>(ctx->d_tris.as<DTri>() + first, ctx->t_vals0.as<uint32_t>(), cnt, ctx->t_tris_tmp.as<DTri>(),
+            // the mesh's triangle records in the order of the tree's leaves, and which triangle each one is (from the copy
+            // in the mesh's own order made below)
+            k_permute_tris<<<div_up(cnt, 256), 256, 0, s>>>(ctx->t_tris_tmp.as<DTri>() + first, ctx->t_vals0.as<uint32_t>(), cnt, ctx->d_tris.as<DTri>() + first,
                                                             ctx->d_tri_ids.as<uint32_t>() + first);
             PT_HIP(ctx, hipGetLastError());
-            PT_HIP(ctx, hipMemcpyAsync(ctx->d_tris.as<DTri>() + first, ctx->t_tris_tmp.p, sizeof(DTri) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
             PT_HIP(ctx, hipMemcpyAsync(ctx->d_blas_order.as<uint32_t>() + first, ctx->t_vals0.p, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
-            rc = collapse_wide(ctx, bn, node_base[m], cnt, true, ctx->d_blas_nodes.as<WNode>() + node_base[m], node_base[m], info + 4, info);
+            return collapse_wide(ctx, bn, node_base[m], cnt, true, ctx->d_blas_nodes.as<WNode>() + node_base[m], node_base[m], info + 4, info);
+        };
+        if (n_nodes) {   // (a copy of the records in mesh order: a BLAS that is built a second time permutes from it again)
+            PT_HIP(ctx, ctx->t_tris_tmp.ensure(sizeof(DTri) * (size_t)n_tris));
+            PT_HIP(ctx, hipMemcpyAsync(ctx->t_tris_tmp.p, ctx->d_tris.p, sizeof(DTri) * (size_t)n_tris, hipMemcpyDeviceToDevice, s));
+        }
+        std::vector<char> used_sah(n_meshes, 0);
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            if (node_base[m] == PT_NONE) continue;
+            // moderate meshes get the better tree from the host, very large ones the fast one from the device
+            used_sah[m] = ctx->blas_sah && hm[m].tri_count <= kSahHostMaxTris;
+            const int rc = build_blas(m, used_sah[m] != 0);
             if (rc != PT_OK) return rc;
         }
         std::vector<uint32_t> infos(8 * (size_t)(n_meshes + 1), 0);
         PT_HIP(ctx, hipMemcpyAsync(infos.data(), ctx->t_info.p, sizeof(uint32_t) * infos.size(), hipMemcpyDeviceToHost, s));
         PT_HIP(ctx, hipStreamSynchronize(s));
+        // The surface-area builder bounds neither the depth of its tree nor, with it, the stack a walk needs: triangles
+        // spaced geometrically make it peel one off per level. The Morton-order tree is at most as deep as its keys
+        // have bits, so a mesh whose tree would leave too little of the traversal stack is built again that way.
+        bool rebuilt = false;
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            if (node_base[m] == PT_NONE || !used_sah[m] || infos[8 * (size_t)m + 4 + 3] <= kBlasNeedMaxSah) continue;
+            PT_HIP(ctx, hipMemsetAsync(ctx->t_info.as<uint32_t>() + 8 * (size_t)m, 0, 8 * sizeof(uint32_t), s));
+            if (ctx->debug) std::fprintf(stderr, "[pt_amd] mesh %u: its surface-area BLAS needs %u stack entries, built again in Morton order\n", m, infos[8 * (size_t)m + 4 + 3]);
+            const int rc = build_blas(m, false);
+            if (rc != PT_OK) return rc;
+            rebuilt = true;
+        }
+        if (rebuilt) {
+            PT_HIP(ctx, hipMemcpyAsync(infos.data(), ctx->t_info.p, sizeof(uint32_t) * infos.size(), hipMemcpyDeviceToHost, s));
+            PT_HIP(ctx, hipStreamSynchronize(s));
+        }
         uint32_t max_depth = 0, max_need = 0;
         std::vector<uint32_t> n_wide(n_meshes, 0);
         for (uint32_t m = 0; m < n_meshes; ++m) {

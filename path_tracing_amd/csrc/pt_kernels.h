@@ -647,7 +647,9 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                     const uint32_t take = want < avail ? want : avail;
                     // (a portion of a split chunk goes to every fourth lane: the lanes between help with its rays, see
                     // closest_hit_list_quad)
-                    const bool quads = PT_QUAD_TRACE && solo && MODE != PT_MODE_LDS && MODE != PT_MODE_TLAS;
+                    // (only when every lane of the wave is idle, which whole-chunk refill guarantees: with a smaller refill
+                    // threshold the quad leaders may still be busy, and the entries then go to the idle lanes one by one)
+                    const bool quads = PT_QUAD_TRACE && solo && MODE != PT_MODE_LDS && MODE != PT_MODE_TLAS && m == ~0ull;
                     const uint32_t rank = quads ? ((lane & 3u) ? 64u : (lane >> 2)) : (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (take != 0u) quad_wave = quads;
                     if (need && rank < take) {

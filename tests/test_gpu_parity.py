@@ -477,7 +477,9 @@ def test_schedule_invariance(name, spp, golden_dir, monkeypatch):
     for env in ({"PT_AMD_SWEEPS": "1"}, {"PT_AMD_SWEEPS": "8"}, {"PT_AMD_NO_COST_HINTS": "1"}, {"PT_AMD_REFILL_MIN": "1"},
                 {"PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_NO_LDS_SCENE": "1", "PT_AMD_SWEEPS": "3"}, {"PT_AMD_NO_LDS_BLAS": "1"}, {"PT_AMD_WALK_QUOTA": "1"}, {"PT_AMD_WALK_QUOTA": "64"},
                 {"PT_AMD_SPLIT_CHUNKS": "0"}, {"PT_AMD_SPLIT_CHUNKS": "0", "PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_SPLIT_CHUNKS": "1", "PT_AMD_NO_LDS_SCENE": "1"},
-                {"PT_AMD_LIST_REGS": "roomy", "PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_LIST_REGS": "roomy", "PT_AMD_SPLIT_FRACTION": "1", "PT_AMD_SPLIT_LOAD": "0"}):
+                {"PT_AMD_LIST_REGS": "roomy", "PT_AMD_NO_LDS_SCENE": "1"}, {"PT_AMD_LIST_REGS": "roomy", "PT_AMD_SPLIT_FRACTION": "1", "PT_AMD_SPLIT_LOAD": "0"},
+                {"PT_AMD_REFILL_MIN": "1", "PT_AMD_SPLIT_FRACTION": "1", "PT_AMD_SPLIT_LOAD": "0", "PT_AMD_NO_LDS_SCENE": "1"},
+                {"PT_AMD_REFILL_MIN": "16", "PT_AMD_SPLIT_FRACTION": "1", "PT_AMD_SPLIT_LOAD": "0"}):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)

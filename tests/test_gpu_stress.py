@@ -132,3 +132,36 @@ def test_origins_far_outside_the_scene():
     rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     a, br = both(scene, scene.frame(), rays)
     assert_identical(a, br)
+
+
+def test_geometrically_spaced_triangles_get_a_tree_the_stack_can_hold(capfd, monkeypatch):
+    """Triangles whose distance from the origin grows by a constant factor: the binned surface-area builder peels a few of
+    them off per level, so its tree (and the stack a walk of it needs) grows with the triangle count; such a mesh is built
+    again in Morton order, whose depth is bounded by the key bits. The scene must render, and as the exhaustive loop does."""
+    n = 280
+    k = np.arange(n, dtype=np.float64)
+    x = 1.25 ** k                                   # 1 ... 1.3e27
+    pos = np.empty((n, 3, 3))
+    pos[:, 0] = np.stack([x, np.zeros(n), np.zeros(n)], axis=1)
+    pos[:, 1] = np.stack([x * 1.1, np.zeros(n), x * 0.1], axis=1)       # counter-clockwise seen from +y
+    pos[:, 2] = np.stack([x * 1.1, np.zeros(n), -x * 0.1], axis=1)
+    b = scenes.SceneBuilder()
+    mesh = b.add_mesh(pos.reshape(-1, 3), np.tile([0.0, 1.0, 0.0], (3 * n, 1)), np.zeros((3 * n, 2)), np.arange(3 * n))
+    b.add_object(mesh, b.add_material(albedo=(0.8, 0.7, 0.6), roughness=1.0))
+    scene = b.build("geometric", scenes.Camera((6.0, 9.0, 0.5), (6.0, 0.0, 0.0)), sky_color=(0.5, 0.6, 0.8), width=96, height=64, samples=2, bounces=3)
+    monkeypatch.setenv("PT_AMD_DEBUG", "1")
+    frame = scene.frame()
+    with abi.Context(accel=abi.PT_ACCEL_BVH) as ctx:
+        ctx.upload_scene(scene)
+        img = ctx.render(frame)
+        acc = ctx.check_accel()
+        prim = ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID)
+    err = capfd.readouterr().err
+    assert "built again in Morton order" in err, err[-400:]
+    assert acc["errors"] == 0
+    with abi.Context(accel=abi.PT_ACCEL_BRUTE) as ctx:
+        ctx.upload_scene(scene)
+        want = ctx.render(frame)
+        assert np.array_equal(prim, ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID))
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+    assert (prim != abi.PT_U32_MAX).sum() > 20
