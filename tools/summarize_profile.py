@@ -4,9 +4,12 @@
     python tools/summarize_profile.py <tag> [--kernel k_paths] [--workload boxes]
 
 Per-launch averages over the dispatches of the chosen kernel:
-  duration from --kernel-trace; SQ counters; HBM traffic from FETCH_SIZE / WRITE_SIZE with the gfx950
-  correction for reads (FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams: doubled for the
-  upper bound, both figures are recorded). FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KiB.
+  duration from --kernel-trace; SQ counters; HBM-side traffic from FETCH_SIZE / WRITE_SIZE (reported by rocprofv3 in KiB).
+  What FETCH_SIZE counts depends on the access pattern, calibrated on this part with tools/fetch_calib.sh
+  (profiles/r03_fetch_calib.txt): it reports half the bytes of a wide coalesced stream (16 B per lane; 2.000 measured) and
+  the bytes themselves of scattered 64-byte record gathers (0.98 measured). The factor applied is --fetch-factor: 2 for
+  the workloads whose misses are streams (path list, parked pixel state, images), 1 for the 83,334-object scene, whose
+  misses are node and object-record gathers. Both raw and corrected figures are recorded.
 Also updates profiles/traffic.json, which bench.py reads for roofline.traffic.
 """
 import argparse
@@ -43,6 +46,7 @@ def main():
     ap.add_argument("--kernel", default="k_paths")
     ap.add_argument("--workload", default="boxes")
     ap.add_argument("--fif-steps", type=int, default=20, help="frames of the timed region in the frames-in-flight trace")
+    ap.add_argument("--fetch-factor", type=float, default=None, help="bytes per byte FETCH_SIZE reports (default: 1 for instanced_boxes, else 2)")
     args = ap.parse_args()
     src = ROOT / "gpurun_out" / f"prof_{args.tag}"
     dst = ROOT / "profiles"
@@ -137,8 +141,10 @@ def main():
     if "FETCH_SIZE" in counters or "WRITE_SIZE" in counters:
         fetch_kib = counters.get("FETCH_SIZE", 0.0)
         write_kib = counters.get("WRITE_SIZE", 0.0)
-        hbm = {"fetch_bytes_raw": fetch_kib * 1024, "fetch_bytes_corrected_x2": fetch_kib * 2048, "write_bytes": write_kib * 1024}
-        hbm["hbm_bytes_per_launch"] = hbm["fetch_bytes_corrected_x2"] + hbm["write_bytes"]
+        factor = args.fetch_factor if args.fetch_factor is not None else (1.0 if args.workload == "instanced_boxes" else 2.0)
+        hbm = {"fetch_bytes_raw": fetch_kib * 1024, "fetch_bytes_corrected_x2": fetch_kib * 2048, "write_bytes": write_kib * 1024,
+               "fetch_factor_applied": factor, "fetch_factor_source": "profiles/r03_fetch_calib.txt"}
+        hbm["hbm_bytes_per_launch"] = hbm["fetch_bytes_raw"] * factor + hbm["write_bytes"]
         if "avg_kernel_ms" in out:
             hbm["GBs"] = hbm["hbm_bytes_per_launch"] / (out["avg_kernel_ms"] * 1e-3) / 1e9
         out["hbm"] = hbm
