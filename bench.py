@@ -190,8 +190,10 @@ def main():
     ctx = ctxs[0]
     bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(F)]
     out = bufs[0]
-    streams = [torch.cuda.Stream(device) for _ in range(F)]
-    stream = streams[0]
+    # (torch streams only where frames are driven through them: a stream that is never used still takes one of the
+    # process's hardware queues, and with HIP's default of four the slots' own streams then have to share)
+    streams = [torch.cuda.Stream(device) for _ in range(F)] if not use_slots else []
+    stream = streams[0] if streams else torch.cuda.current_stream(device)
     comm_stream = torch.cuda.Stream(device) if world > 1 else None
     rendered = [torch.cuda.Event() for _ in bufs]
     reduced = [torch.cuda.Event() for _ in bufs]
@@ -445,6 +447,7 @@ def main():
         extra["ms_per_step_plugin_sync"] = round(float(np.median(timed(PluginSync(ctx, host16[0]), repeats=n_rep_other))) / args.steps * 1e3, 4)
         extra["ms_per_step_plugin_async"] = round(float(np.median(timed(Slots(ctx, F, host=host16, f16=True), repeats=n_rep_other))) / args.steps * 1e3, 4)
         # the arrangement of earlier records: one context (and one copy of the scene) per frame in flight
+        streams.extend(torch.cuda.Stream(device) for _ in range(F))
         cs_f = [abi.Context(device=local_rank) for _ in range(F)]
         for c in cs_f:
             c.upload_scene(scene)

@@ -82,7 +82,9 @@ struct FrameKey {
 // device-side work buffers of the lane are shared by the two, which stream order makes safe.
 struct FrameSlot {
     hipEvent_t ev0 = nullptr, evm = nullptr, ev1 = nullptr;
-    DevBuf counters, counters_k1;
+    DevBuf counters;
+    DCounters* h_counters = nullptr;      // page-locked copies, written behind the frame on its own stream: reading a frame's
+    DCounters* h_counters_k1 = nullptr;   // record never goes through the null stream, whose hardware queue a frame stream may share
     bool pending = false;   // enqueued, not read back yet
     bool detail = false;    // rendered with detailed statistics
     uint32_t obj_set = 0;   // the object set (instances + TLAS) the frame reads
@@ -202,6 +204,7 @@ struct pt_ctx {
     bool k1_narrow = false;       // k_primary with four waves per workgroup even where sixteen fit (PT_AMD_K1_NARROW)
     int blocks_per_cu = 0;        // workgroups of k_paths per compute unit at most (PT_AMD_BLOCKS_PER_CU; 0: what fits)
     bool debug = false;           // PT_AMD_DEBUG: a line per frame on stderr
+    bool slot_priority = true;    // see lane_init
     uint32_t lds_per_cu = 160 * 1024;
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
     uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
@@ -521,6 +524,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (std::getenv("PT_AMD_K1_NARROW")) ctx->k1_narrow = true;
         if (const char* e = std::getenv("PT_AMD_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->blocks_per_cu = v; }
         if (std::getenv("PT_AMD_DEBUG")) ctx->debug = true;
+        if (const char* e = std::getenv("PT_AMD_SLOT_PRIORITY")) ctx->slot_priority = std::atoi(e) != 0;
         if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
         if (std::getenv("PT_AMD_NO_QUEUE_AHEAD")) ctx->queue_ahead = false;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
@@ -584,7 +588,8 @@ int pt_destroy(pt_ctx* ctx) {
         for (DevBuf* b : L.bufs) b->release();
         for (FrameSlot& sl : L.slot) {
             sl.counters.release();
-            sl.counters_k1.release();
+            if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+            if (sl.h_counters_k1) (void)hipHostFree(sl.h_counters_k1);
             if (sl.ev0) (void)hipEventDestroy(sl.ev0);
             if (sl.ev1) (void)hipEventDestroy(sl.ev1);
             if (sl.evm) (void)hipEventDestroy(sl.evm);
@@ -872,14 +877,25 @@ namespace {
 hipError_t lane_init(pt_ctx* ctx, Lane& L, bool own_stream) {
     if (L.ready) return hipSuccess;
     hipError_t e = hipSuccess;
-    if (own_stream) e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+    if (own_stream) {
+        // A priority of its own kind: the runtime keeps the hardware queues of each priority apart, so the slots' streams
+        // do not have to share the few queues a process has by default (four) with its other streams (the null stream, the
+        // context's upload stream, the host application's own), which would make two slots run their frames one after
+        // the other. PT_AMD_SLOT_PRIORITY=0 creates them with the default priority.
+        int lo = 0, hi = 0;
+        if (ctx->slot_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+            e = hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, hi);
+        else
+            e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+    }
     else L.stream = ctx->stream;
     for (FrameSlot& sl : L.slot) {
         if (e == hipSuccess && !sl.ev0) e = hipEventCreate(&sl.ev0);
         if (e == hipSuccess && !sl.ev1) e = hipEventCreate(&sl.ev1);
         if (e == hipSuccess && !sl.evm) e = hipEventCreate(&sl.evm);
         if (e == hipSuccess) e = sl.counters.ensure(sizeof(DCounters));
-        if (e == hipSuccess) e = sl.counters_k1.ensure(sizeof(DCounters));
+        if (e == hipSuccess && !sl.h_counters) e = hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters), sizeof(DCounters), hipHostMallocDefault);
+        if (e == hipSuccess && !sl.h_counters_k1) e = hipHostMalloc(reinterpret_cast<void**>(&sl.h_counters_k1), sizeof(DCounters), hipHostMallocDefault);
     }
     L.ready = e == hipSuccess;
     return e;
@@ -1101,8 +1117,7 @@ int finish_slot(pt_ctx* ctx, Lane& L, FrameSlot& sl) {
     PT_HIP(ctx, hipEventSynchronize(sl.ev1));
     float ms = 0.0f;
     PT_HIP(ctx, hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
-    DCounters c;
-    PT_HIP(ctx, hipMemcpy(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    const DCounters c = *sl.h_counters;   // (copied behind the frame, before the event)
     float ms_primary = 0.0f;
     PT_HIP(ctx, hipEventElapsedTime(&ms_primary, sl.ev0, sl.evm));
     if (ctx->debug) std::fprintf(stderr, "[pt_amd] frame done: %.3f ms, work / longest chunk %u waves, %u chunks in parts, workgroups wanted %u, other frames running at its start %u\n", ms, c.waves_needed, c.n_split, c.n_groups, c.others_running);
@@ -1119,8 +1134,7 @@ int finish_slot(pt_ctx* ctx, Lane& L, FrameSlot& sl) {
     st.hits = c.hits;
     st.primary_xforms = st.primary_box_tests = st.primary_tri_tests = st.primary_hits = 0;
     if (sl.detail) {
-        DCounters k1;
-        PT_HIP(ctx, hipMemcpy(&k1, sl.counters_k1.p, sizeof k1, hipMemcpyDeviceToHost));
+        const DCounters k1 = *sl.h_counters_k1;
         st.primary_xforms = k1.xforms;
         st.primary_box_tests = k1.box_tests;
         st.primary_tri_tests = k1.tri_tests;
@@ -1376,7 +1390,7 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
         }
     }
     if (st) {
-        PT_HIP(ctx, hipMemcpyAsync(sl.counters_k1.p, sl.counters.p, sizeof(DCounters), hipMemcpyDeviceToDevice, s));
+        PT_HIP(ctx, hipMemcpyAsync(sl.h_counters_k1, sl.counters.p, sizeof(DCounters), hipMemcpyDeviceToHost, s));
     }
     if (!noalloc) PT_HIP(ctx, hipEventRecord(sl.evm, s));
     // 2. path pass: persistent waves, as many workgroups as fit on the chip at once (fewer for small frames); they
@@ -1581,6 +1595,7 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
         k_pack_f16<<<div_up((uint32_t)n_pix, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(out), out16, (uint32_t)n_pix);
         PT_HIP(ctx, hipGetLastError());
     }
+    PT_HIP(ctx, hipMemcpyAsync(sl.h_counters, sl.counters.p, sizeof(DCounters), hipMemcpyDeviceToHost, s));
     PT_HIP(ctx, hipEventRecord(sl.ev1, s));
     sl.pending = true;
     sl.obj_set = ctx->cur_set;
