@@ -155,8 +155,9 @@ def main():
             cmd += ["--spp", str(args.spp)]
         if args.fixed_time:
             cmd += ["--fixed-time"]
+        print("[bench] child process with the default hardware-queue count ...", file=sys.stderr, flush=True)
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=900)   # (its progress lines go to this process's stderr)
             child_extra["ms_per_step_default_hw_queues"] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
         except Exception as e:   # (reported, not fatal: the headline does not depend on it)
             child_extra["ms_per_step_default_hw_queues"] = None
@@ -415,6 +416,8 @@ def main():
                 dt_r = float(tm[0].item())
             out_s.append(dt_r)
             r += 1
+            if rank == 0:   # (a line of progress per repeat: long workloads would otherwise be silent for minutes)
+                print(f"[bench] {type(run).__name__}: repeat {r} of {reps}: {dt_r / args.steps * 1e3:.4f} ms per step", file=sys.stderr, flush=True)
             if r == 1 and not repeats:   # repeats of seconds each: fewer of them (every rank sees the same max-reduced time)
                 reps = max(1, min(reps, int(8.0 / max(dt_r, 1e-9))))
         return out_s
