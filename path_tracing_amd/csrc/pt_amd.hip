@@ -861,7 +861,11 @@ int pt_upload_objects(pt_ctx* ctx, const PtObject* objects, uint32_t n_objects) 
             ctx->cur_set = target;
             return PT_OK;
         }
-        return rebuild_objects(ctx, target);
+        const int rc_build = rebuild_objects(ctx, target);
+        // (a build that failed half-way leaves no usable version: the array on record is the new one, the current version
+        // still the old one's, so it must not pass for built; frames in flight keep what they were enqueued with)
+        if (rc_build != PT_OK) ctx->sets[ctx->cur_set].built = false;
+        return rc_build;
     } catch (const std::bad_alloc&) {
         return fail(ctx, PT_ERR_OUT_OF_MEMORY, "pt_upload_objects: host allocation failed");
     } catch (...) {

@@ -1,6 +1,8 @@
 // pt_render_cli — renders the Cornell box of reference examples/cornellbox.rs:59-113 through the C++ plugin mirror
 // and writes a raw little-endian f32 RGBA file plus a checksum line. Used as the compiled-host smoke test.
-//   pt_render_cli <width> <height> <samples> <bounces> <out.f32>
+//   pt_render_cli <width> <height> <samples> <bounces> <out.f32> [frames in flight K [frames N]]
+// With K given it also renders N frames (default 6) with `time` = 0.5, 1.5, ... keeping K of them in flight on the slots
+// of the one context (RayTraceNode::submit / wait, page-locked targets) and appends them to the output file in order.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -112,6 +114,34 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < img.size(); i += 4) sum += img[i] + img[i + 1] + img[i + 2];
         std::printf("ok %ux%u spp=%u bounces=%u rays=%llu trace_ms=%.3f mean=%.6f\n", W, H, settings.samples, settings.bounces,
                     (unsigned long long)st.rays, st.trace_ms, sum / (3.0 * W * H));
+        if (argc > 6) {
+            const uint32_t K = (uint32_t)std::atoi(argv[6]), N = argc > 7 ? (uint32_t)std::atoi(argv[7]) : 6u;
+            if (K < 1 || K > PT_MAX_FRAME_SLOTS) { std::fprintf(stderr, "frames in flight must be 1..%u\n", PT_MAX_FRAME_SLOTS); return 2; }
+            const size_t n_floats = (size_t)W * H * 4;
+            std::vector<float*> staging(K, nullptr);
+            for (uint32_t k = 0; k < K; ++k) {
+                void* p = nullptr;
+                plugin.check(pt_host_alloc(plugin.context(), n_floats * sizeof(float), &p));
+                staging[k] = static_cast<float*>(p);
+            }
+            fo = std::fopen(argv[5], "ab");
+            if (!fo) { std::perror("fopen"); return 1; }
+            for (uint32_t n = 0; n < N + K; ++n) {
+                const uint32_t slot = n % K;
+                if (n >= K) {   // the frame this slot has held since K submits ago
+                    plugin.node.wait(slot);
+                    std::fwrite(staging[slot], sizeof(float), n_floats, fo);
+                }
+                if (n < N) {
+                    Globals g;
+                    g.time = 0.5f + (float)n;
+                    meta.objects_dirty = true;   // extract_visible hands the objects over every frame
+                    if (!plugin.node.submit(view, g, &settings, slot, staging[slot])) { std::fprintf(stderr, "submit refused\n"); return 1; }
+                }
+            }
+            std::fclose(fo);
+            std::printf("ok %u frames with %u in flight\n", N, K);
+        }
         // error path: an object pointing past the mesh table must come back as an exception, not a crash
         meta.objects[0].mesh = 99;
         meta.objects_dirty = true;

@@ -141,8 +141,15 @@ public:
     // Renders the view into `target` (width*height*4 floats, row 0 on top). Returns false without touching
     // `target` when the plugin is not ready or the camera has no settings.
     bool run(const View& view, const Globals& globals, const RayTraceSettings* settings, std::vector<float>& target, uint32_t flags = 0);
+    // The same pass with frames in flight (pt_render_submit / pt_render_wait): `submit` enqueues the view's frame on `slot`
+    // (0 .. PT_MAX_FRAME_SLOTS - 1) and returns; `target` (width*height*4 floats, best from pt_host_alloc) holds the image
+    // once `wait(slot)` has returned. A node that keeps K frames in flight submits frame n to slot n % K and waits for
+    // that slot right before it submits to it again. Returns false (nothing enqueued) when the plugin is not ready.
+    bool submit(const View& view, const Globals& globals, const RayTraceSettings* settings, uint32_t slot, float* target, uint32_t flags = 0);
+    void wait(uint32_t slot);
 
 private:
+    static PtFrame make_frame(const View& view, const Globals& globals, const RayTraceSettings& settings, uint32_t flags);
     RayTracePlugin* plugin_;
 };
 
@@ -189,23 +196,38 @@ private:
     pt_ctx* ctx_ = nullptr;
 };
 
-inline bool RayTraceNode::run(const View& view, const Globals& globals, const RayTraceSettings* settings, std::vector<float>& target, uint32_t flags) {
-    if (!plugin_->ready() || settings == nullptr) return false;
-    plugin_->prepare();
+inline PtFrame RayTraceNode::make_frame(const View& view, const Globals& globals, const RayTraceSettings& settings, uint32_t flags) {
     PtFrame f{};
     for (int i = 0; i < 16; ++i) { f.world_from_view[i] = view.world_from_view[i]; f.view_from_clip[i] = view.view_from_clip[i]; }
     f.width = (uint32_t)view.viewport[2];
     f.height = (uint32_t)view.viewport[3];
     f.time = globals.time;
     f.flags = flags;
-    f.settings.bounces = settings->bounces;
-    f.settings.samples = settings->samples;
-    for (int i = 0; i < 4; ++i) f.settings.sky_color[i] = settings->sky_color[i];
+    f.settings.bounces = settings.bounces;
+    f.settings.samples = settings.samples;
+    for (int i = 0; i < 4; ++i) f.settings.sky_color[i] = settings.sky_color[i];
     f.part_index = 0;
     f.part_count = 1;
+    return f;
+}
+
+inline bool RayTraceNode::run(const View& view, const Globals& globals, const RayTraceSettings* settings, std::vector<float>& target, uint32_t flags) {
+    if (!plugin_->ready() || settings == nullptr) return false;
+    plugin_->prepare();
+    const PtFrame f = make_frame(view, globals, *settings, flags);
     target.resize((size_t)f.width * f.height * 4);
     plugin_->check(pt_render(plugin_->context(), &f, target.data()));
     return true;
 }
+
+inline bool RayTraceNode::submit(const View& view, const Globals& globals, const RayTraceSettings* settings, uint32_t slot, float* target, uint32_t flags) {
+    if (!plugin_->ready() || settings == nullptr) return false;
+    plugin_->prepare();   // (an object upload here does not wait for the frames in flight: they keep their version)
+    const PtFrame f = make_frame(view, globals, *settings, flags);
+    plugin_->check(pt_render_submit(plugin_->context(), &f, slot, target));
+    return true;
+}
+
+inline void RayTraceNode::wait(uint32_t slot) { plugin_->check(pt_render_wait(plugin_->context(), slot)); }
 
 }  // namespace path_tracing

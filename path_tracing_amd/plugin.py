@@ -106,6 +106,23 @@ class RayTraceNode:
                                flags=flags, part_index=part_index, part_count=part_count)
         return p.ctx.render(frame)
 
+    def submit(self, view: View, globals_: Globals, settings: RayTraceSettings | None, slot: int, target: np.ndarray, *, flags: int = 0) -> bool:
+        """The same pass with frames in flight (pt_render_submit): enqueue the view's frame on `slot` and return; `target`
+        (from plugin.ctx.host_array) holds the image once wait(slot) has returned. Returns False when nothing was enqueued
+        (plugin not ready, camera without settings), as `run` returns None then."""
+        p = self._plugin
+        if p.ctx is None or settings is None or view is None or globals_ is None:
+            return False
+        p.prepare()    # (an object upload here does not wait for the frames in flight: they keep their version)
+        w, h = int(view.viewport[2]), int(view.viewport[3])
+        frame = abi.make_frame(view.world_from_view, view.view_from_clip, w, h, time=globals_.time,
+                               bounces=settings.bounces, samples=settings.samples, sky_color=tuple(settings.sky_color)[:4], flags=flags)
+        p.ctx.submit(frame, slot, target)
+        return True
+
+    def wait(self, slot: int):
+        self._plugin.ctx.wait(slot)
+
 
 class RayTracePlugin:
     """reference src/shader.rs:35-104 (`impl Plugin for RayTracePlugin`)."""

@@ -875,11 +875,23 @@ def test_plugin_mirror_renders_like_the_raw_abi():
         # objects change every frame in the reference (extract_visible); re-upload and render again
         plugin.meta.set_objects(scene.objects)
         img2 = plugin.node.run(view, Globals(0.0), settings)
+        # the same node with two frames in flight, the objects handed over before each
+        bufs = [plugin.ctx.host_array((54, 96, 4), np.float32) for _ in range(2)]
+        assert not plugin.node.submit(view, Globals(0.0), None, 0, bufs[0])
+        for k in range(2):
+            plugin.meta.set_objects(scene.objects)
+            assert plugin.node.submit(view, Globals(0.5 + k), settings, k, bufs[k])
+        flight = []
+        for k in range(2):
+            plugin.node.wait(k)
+            flight.append(bufs[k].copy())
     finally:
         plugin.close()
     ref = oracle_render(scene, scene.frame())
     assert np.array_equal(img.view(np.uint32), ref["image"].view(np.uint32))
     assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
+    for k in range(2):
+        assert np.array_equal(flight[k].view(np.uint32), oracle_render(scene, scene.frame(time=0.5 + k))["image"].view(np.uint32))
 
 
 def test_every_texture_format_branch_reaches_the_kernels():
@@ -956,3 +968,11 @@ def test_cpp_host_mirror_cli(tmp_path):
     ref = oracle_render(scene, scene.frame())["image"]
     assert rrmse(img, ref) <= RRMSE_TOL
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    # the same host with three frames in flight on the slots of its one context: six frames, `time` advancing
+    r = subprocess.run([str(exe), "48", "32", "3", "6", str(out), "3", "6"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "6 frames with 3 in flight" in r.stdout, r.stdout + r.stderr
+    frames = np.fromfile(out, dtype=np.float32).reshape(7, 32, 48, 4)
+    assert np.array_equal(frames[0].view(np.uint32), ref.view(np.uint32))
+    for n in range(6):
+        want = oracle_render(scene, scene.frame(time=0.5 + n))["image"]
+        assert np.array_equal(frames[1 + n].view(np.uint32), want.view(np.uint32)), f"frame {n}" 
