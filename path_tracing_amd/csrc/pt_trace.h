@@ -54,6 +54,9 @@ struct LdsStack {
     uint32_t* base;  // &s_stack[wave][0][lane]
     PT_DEV void put(int level, uint32_t v) { base[level * 64] = v; }
     PT_DEV uint32_t get(int level) const { return base[level * 64]; }
+    PT_DEV bool all_in_lds(int) const { return true; }
+    PT_DEV void put_lds(int level, uint32_t v) { base[level * 64] = v; }
+    PT_DEV uint32_t get_lds(int level) const { return base[level * 64]; }
 };
 // The same with only the first `lds_levels` entries in LDS and the rest in a column of global memory per lane: a walk
 // rarely holds more than a dozen entries, but the trees allow several times that, and LDS per workgroup decides how many
@@ -71,6 +74,11 @@ struct SpillStack {
         if (level < lds_levels) return base[level * 64];
         return overflow[(size_t)(level - lds_levels) * stride];
     }
+    // Wave-uniform: no lane of the wave touches a level at or above `top` that lies outside LDS, so the plain LDS
+    // accessors below may be used (the usual case; the per-access choice above costs a dozen instructions each time).
+    PT_DEV bool all_in_lds(int top) const { return !__any(top > lds_levels); }
+    PT_DEV void put_lds(int level, uint32_t v) { base[level * 64] = v; }
+    PT_DEV uint32_t get_lds(int level) const { return base[level * 64]; }
 };
 
 PT_DEV bool candidate_wins(float t, uint32_t obj, uint32_t tri, const Best& b, uint32_t tie_lowest) {
@@ -252,6 +260,14 @@ PT_DEV uint32_t wide_visit(const uint4 q0, const uint4 q1, const uint4 q2, const
 #undef PT_CE
     const int n_hit = (key[0] != 0xFFFFFFFFu) + (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
     const int n_push = n_hit > 1 ? n_hit - 1 : 0;
+    // (levels sp - 1 .. sp + 5 are touched below)
+    if (stk.all_in_lds(sp + 6)) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) stk.put_lds(sp + ((key[j] != 0xFFFFFFFFu) ? n_push - j : n_push + j - 1), ref[j]);
+        sp += n_push;
+        if (n_hit) return ref[0];
+        return (sp > sp0) ? stk.get_lds(--sp) : PT_WALK_DONE;
+    }
 #pragma unroll
     for (int j = 1; j < 4; ++j) stk.put(sp + ((key[j] != 0xFFFFFFFFu) ? n_push - j : n_push + j - 1), ref[j]);
     sp += n_push;
