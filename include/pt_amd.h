@@ -289,6 +289,22 @@ int pt_render_submit(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* out
 int pt_render_submit_device(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* out_rgba_device);
 int pt_render_wait(pt_ctx* ctx, uint32_t slot);
 
+/* Ordering a slot's frame against the caller's own GPU work without blocking the host.
+ * The reference's pass is one node of a render graph (between Node3d::EndMainPass and
+ * Node3d::MotionBlur, reference src/shader.rs:83-88): what reads its image -- motion
+ * blur, bloom, TAA, tonemapping -- runs on the GPU behind it, and the host never waits.
+ *  - pt_render_stream_wait: work enqueued on `hip_stream` after this call starts when
+ *    the frame submitted to `slot` (and the copy of its image, if any) is complete.
+ *    PT_ERR_NOT_READY when the slot holds no submitted frame. The slot still has to be
+ *    waited for with pt_render_wait before its next submit.
+ *  - pt_render_slot_wait_for: whatever is submitted to `slot` after this call starts
+ *    when the work enqueued on `hip_stream` so far is complete (e.g. the last reader
+ *    of the image buffer the next frame will overwrite).
+ * `hip_stream`: a hipStream_t of the context's device; null: the context's own stream
+ * (the one pt_render and pt_render_device(..., null) run on). */
+int pt_render_stream_wait(pt_ctx* ctx, uint32_t slot, void* hip_stream);
+int pt_render_slot_wait_for(pt_ctx* ctx, uint32_t slot, void* hip_stream);
+
 /* Page-locked host memory owned by the context, for the image pt_render returns
  * (and for the arrays handed to pt_upload_*): copies to and from it run at the
  * PCIe rate, about three times the rate of pageable memory on the test machine.

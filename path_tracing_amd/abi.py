@@ -114,6 +114,7 @@ EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_u
            "pt_upload_objects", "pt_render", "pt_render_device", "pt_query", "pt_read_aux",
            "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log", "pt_host_alloc", "pt_host_free",
            "pt_render_device_noalloc", "pt_render_submit", "pt_render_submit_device", "pt_render_wait",
+           "pt_render_stream_wait", "pt_render_slot_wait_for",
            "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_upload_meshes", "pt_multi_upload_materials",
            "pt_multi_upload_objects", "pt_multi_render", "pt_multi_context", "pt_multi_rccl_version"]
 
@@ -154,6 +155,8 @@ def load_library():
     lib.pt_render_submit.argtypes = [vp, C.POINTER(PtFrame), u32, vp]
     lib.pt_render_submit_device.argtypes = [vp, C.POINTER(PtFrame), u32, vp]
     lib.pt_render_wait.argtypes = [vp, u32]
+    lib.pt_render_stream_wait.argtypes = [vp, u32, vp]
+    lib.pt_render_slot_wait_for.argtypes = [vp, u32, vp]
     lib.pt_query.argtypes = [vp, vp, u32, vp]
     lib.pt_read_aux.argtypes = [vp, u32, vp, C.c_size_t]
     lib.pt_set_stats_detail.argtypes = [vp, i32]
@@ -388,6 +391,16 @@ class Context:
     def wait(self, slot: int):
         """pt_render_wait: blocks until the frame submitted to `slot` is complete; stats()/read_aux() then describe it."""
         self._check(self._lib.pt_render_wait(self._h, slot))
+
+    def stream_wait(self, slot: int, stream: int = 0):
+        """pt_render_stream_wait: work enqueued on the HIP stream `stream` from now on starts when the frame submitted to
+        `slot` is complete; the host does not block (0: the context's own stream)."""
+        self._check(self._lib.pt_render_stream_wait(self._h, slot, C.c_void_p(stream) if stream else None))
+
+    def slot_wait_for(self, slot: int, stream: int = 0):
+        """pt_render_slot_wait_for: what is submitted to `slot` from now on starts when the work enqueued on `stream` so far
+        is complete."""
+        self._check(self._lib.pt_render_slot_wait_for(self._h, slot, C.c_void_p(stream) if stream else None))
 
     def query(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)

@@ -114,6 +114,8 @@ struct Lane {
     FrameKey hint_key;
     uint32_t aux_w = 0, aux_h = 0;
     bool submitted = false;           // pt_render_submit without its pt_render_wait yet
+    hipEvent_t ev_done = nullptr;     // slot lanes: behind the submitted frame and the copy of its image (pt_render_stream_wait)
+    hipEvent_t ev_dep = nullptr;      // slot lanes: what the slot's next work waits for (pt_render_slot_wait_for)
     PtStats stats{};
     DevBuf* bufs[14] = {&d_stack_overflow, &d_out, &d_out16, &d_aux_obj, &d_aux_flat, &d_aux_t, &d_aux_rays, &d_paths, &d_sweeps_done, &d_carry,
                         &d_cost, &d_chunk_bin, &d_chunk_order, &d_wave_log};
@@ -594,6 +596,8 @@ int pt_destroy(pt_ctx* ctx) {
             if (sl.ev1) (void)hipEventDestroy(sl.ev1);
             if (sl.evm) (void)hipEventDestroy(sl.evm);
         }
+        if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+        if (L.ev_dep) (void)hipEventDestroy(L.ev_dep);
         if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
     }
     if (ctx->evb0) (void)hipEventDestroy(ctx->evb0);
@@ -893,6 +897,10 @@ hipError_t lane_init(pt_ctx* ctx, Lane& L, bool own_stream) {
             e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
     }
     else L.stream = ctx->stream;
+    if (own_stream) {
+        if (e == hipSuccess && !L.ev_done) e = hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming);
+        if (e == hipSuccess && !L.ev_dep) e = hipEventCreateWithFlags(&L.ev_dep, hipEventDisableTiming);
+    }
     for (FrameSlot& sl : L.slot) {
         if (e == hipSuccess && !sl.ev0) e = hipEventCreate(&sl.ev0);
         if (e == hipSuccess && !sl.ev1) e = hipEventCreate(&sl.ev1);
@@ -1710,7 +1718,8 @@ int submit_frame(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* host, v
     int rc = render_enqueue(ctx, L, frame, out32, L.stream, out16);
     if (rc != PT_OK) return rc;
     if (host) PT_HIP(ctx, hipMemcpyAsync(host, f16 ? static_cast<const void*>(out16) : static_cast<const void*>(out32), (f16 ? 8 : 16) * n_pix, hipMemcpyDeviceToHost, L.stream));
-    L.submitted = true;
+    L.submitted = true;   // (from here on the slot has to be waited for, whatever the record below returns)
+    PT_HIP(ctx, hipEventRecord(L.ev_done, L.stream));
     return PT_OK;
 }
 
@@ -1751,6 +1760,38 @@ int pt_render_wait(pt_ctx* ctx, uint32_t slot) {
         return finish_lane(ctx, L);
     } catch (...) {
         return fail(ctx, PT_ERR_DEVICE, "pt_render_wait: unexpected exception");
+    }
+}
+
+int pt_render_stream_wait(pt_ctx* ctx, uint32_t slot, void* hip_stream) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (slot >= kMaxFrameSlots) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_stream_wait: slot >= PT_MAX_FRAME_SLOTS");
+        Lane& L = ctx->lanes[1u + slot];
+        if (!L.submitted) return fail(ctx, PT_ERR_NOT_READY, "pt_render_stream_wait: no frame has been submitted to slot " + std::to_string(slot));
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        PT_HIP(ctx, hipStreamWaitEvent(hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream, L.ev_done, 0));
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_render_stream_wait: unexpected exception");
+    }
+}
+
+int pt_render_slot_wait_for(pt_ctx* ctx, uint32_t slot, void* hip_stream) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (slot >= kMaxFrameSlots) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_render_slot_wait_for: slot >= PT_MAX_FRAME_SLOTS");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        Lane& L = ctx->lanes[1u + slot];
+        if (!L.ready) {
+            const hipError_t e = lane_init(ctx, L, true);
+            if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE, std::string("pt_render_slot_wait_for: ") + hipGetErrorString(e));
+        }
+        PT_HIP(ctx, hipEventRecord(L.ev_dep, hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream));
+        PT_HIP(ctx, hipStreamWaitEvent(L.stream, L.ev_dep, 0));
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_render_slot_wait_for: unexpected exception");
     }
 }
 

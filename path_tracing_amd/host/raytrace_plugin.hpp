@@ -147,6 +147,13 @@ public:
     // that slot right before it submits to it again. Returns false (nothing enqueued) when the plugin is not ready.
     bool submit(const View& view, const Globals& globals, const RayTraceSettings* settings, uint32_t slot, float* target, uint32_t flags = 0);
     void wait(uint32_t slot);
+    // For a renderer whose later passes read the image on the GPU (the reference's node sits between EndMainPass and MotionBlur,
+    // src/shader.rs:83-88): `submit_device` leaves the image in device memory at `device_target`; `stream_wait` orders the work
+    // enqueued on `hip_stream` afterwards behind the slot's frame, `slot_wait_for` the slot's next frame behind the work enqueued
+    // on `hip_stream` so far. Neither blocks the host; `wait(slot)` is still due before the slot's next submit.
+    bool submit_device(const View& view, const Globals& globals, const RayTraceSettings* settings, uint32_t slot, void* device_target, uint32_t flags = 0);
+    void stream_wait(uint32_t slot, void* hip_stream);
+    void slot_wait_for(uint32_t slot, void* hip_stream);
 
 private:
     static PtFrame make_frame(const View& view, const Globals& globals, const RayTraceSettings& settings, uint32_t flags);
@@ -229,5 +236,16 @@ inline bool RayTraceNode::submit(const View& view, const Globals& globals, const
 }
 
 inline void RayTraceNode::wait(uint32_t slot) { plugin_->check(pt_render_wait(plugin_->context(), slot)); }
+
+inline bool RayTraceNode::submit_device(const View& view, const Globals& globals, const RayTraceSettings* settings, uint32_t slot, void* device_target, uint32_t flags) {
+    if (!plugin_->ready() || settings == nullptr) return false;
+    plugin_->prepare();
+    const PtFrame f = make_frame(view, globals, *settings, flags);
+    plugin_->check(pt_render_submit_device(plugin_->context(), &f, slot, device_target));
+    return true;
+}
+
+inline void RayTraceNode::stream_wait(uint32_t slot, void* hip_stream) { plugin_->check(pt_render_stream_wait(plugin_->context(), slot, hip_stream)); }
+inline void RayTraceNode::slot_wait_for(uint32_t slot, void* hip_stream) { plugin_->check(pt_render_slot_wait_for(plugin_->context(), slot, hip_stream)); }
 
 }  // namespace path_tracing

@@ -123,6 +123,27 @@ class RayTraceNode:
     def wait(self, slot: int):
         self._plugin.ctx.wait(slot)
 
+    def submit_device(self, view: View, globals_: Globals, settings: RayTraceSettings | None, slot: int, device_ptr: int, *, flags: int = 0) -> bool:
+        """`submit` with the image left in device memory at `device_ptr`, for a renderer whose later passes read it on the GPU
+        (the reference's node sits between EndMainPass and MotionBlur, src/shader.rs:83-88)."""
+        p = self._plugin
+        if p.ctx is None or settings is None or view is None or globals_ is None:
+            return False
+        p.prepare()
+        w, h = int(view.viewport[2]), int(view.viewport[3])
+        frame = abi.make_frame(view.world_from_view, view.view_from_clip, w, h, time=globals_.time,
+                               bounces=settings.bounces, samples=settings.samples, sky_color=tuple(settings.sky_color)[:4], flags=flags)
+        p.ctx.submit_device(frame, slot, device_ptr)
+        return True
+
+    def stream_wait(self, slot: int, stream: int = 0):
+        """Work enqueued on the HIP stream `stream` from now on starts when the slot's frame is complete (no host wait)."""
+        self._plugin.ctx.stream_wait(slot, stream)
+
+    def slot_wait_for(self, slot: int, stream: int = 0):
+        """What is submitted to `slot` from now on starts when the work enqueued on `stream` so far is complete."""
+        self._plugin.ctx.slot_wait_for(slot, stream)
+
 
 class RayTracePlugin:
     """reference src/shader.rs:35-104 (`impl Plugin for RayTracePlugin`)."""

@@ -209,6 +209,10 @@ extern "C" {
     pub fn pt_render_submit_device(ctx: *mut pt_ctx, frame: *const PtFrame, slot: u32, out_rgba_device: *mut c_void) -> c_int;
     /// Blocks until the frame submitted to `slot` (and its copy) is complete.
     pub fn pt_render_wait(ctx: *mut pt_ctx, slot: u32) -> c_int;
+    /// GPU-side ordering, no host wait: work enqueued on `hip_stream` afterwards starts when the slot's frame is complete.
+    pub fn pt_render_stream_wait(ctx: *mut pt_ctx, slot: u32, hip_stream: *mut c_void) -> c_int;
+    /// ... and what is submitted to `slot` afterwards starts when the work enqueued on `hip_stream` so far is complete.
+    pub fn pt_render_slot_wait_for(ctx: *mut pt_ctx, slot: u32, hip_stream: *mut c_void) -> c_int;
     pub fn pt_multi_create(cfg: *const PtMultiConfig, out: *mut *mut pt_multi) -> c_int;
     pub fn pt_multi_destroy(m: *mut pt_multi) -> c_int;
     pub fn pt_multi_last_error(m: *const pt_multi) -> *const c_char;
@@ -326,6 +330,24 @@ impl Context {
     /// Blocks until the frame submitted to `slot` is complete.
     pub fn wait(&mut self, slot: u32) -> Result<(), PtError> {
         let rc = unsafe { pt_render_wait(self.raw, slot) };
+        self.check(rc)
+    }
+
+    /// Orders the caller's stream behind the frame of `slot` on the GPU (the render graph's downstream nodes).
+    ///
+    /// # Safety
+    /// `hip_stream` must be a live hipStream_t of the context's device, or null for the context's own stream.
+    pub unsafe fn stream_wait(&mut self, slot: u32, hip_stream: *mut c_void) -> Result<(), PtError> {
+        let rc = pt_render_stream_wait(self.raw, slot, hip_stream);
+        self.check(rc)
+    }
+
+    /// Orders the slot's next frame behind the work enqueued on `hip_stream` so far.
+    ///
+    /// # Safety
+    /// As for `stream_wait`.
+    pub unsafe fn slot_wait_for(&mut self, slot: u32, hip_stream: *mut c_void) -> Result<(), PtError> {
+        let rc = pt_render_slot_wait_for(self.raw, slot, hip_stream);
         self.check(rc)
     }
 

@@ -201,3 +201,62 @@ def test_frames_in_flight_at_1080p_equal_one_at_a_time():
                 ctx.wait(s)
                 assert np.array_equal(bufs[s].view(np.uint32), want[s].view(np.uint32)), f"pass {rep}, slot {s}"
                 assert ctx.stats()["rays"] > 0
+
+
+def test_gpu_side_ordering_of_a_slot_against_a_consumer_stream():
+    """pt_render_stream_wait / pt_render_slot_wait_for: a consumer on a stream of its own (here: a slow chain of device copies
+    that ends by saving the slot's image) reads every frame behind the frame and before the slot's next frame overwrites it,
+    without the host waiting for either. The node of the reference sits in a render graph whose later nodes read its image on
+    the GPU (src/shader.rs:83-88)."""
+    import ctypes as C
+    scene = scenes.boxes(160, 90, 8, 10)
+    n_frames, k_slots = 7, 2
+    times = [0.5 + i for i in range(n_frames)]
+    abi.load_library()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    D2D, D2H = 3, 2
+    nbytes = scene.height * scene.width * 16
+    junk_bytes = 256 << 20
+    ptrs = [C.c_void_p() for _ in range(k_slots + 3)]
+    sizes = [nbytes] * k_slots + [nbytes * n_frames, junk_bytes, junk_bytes]
+    for p, sz in zip(ptrs, sizes):
+        assert hip.hipMalloc(C.byref(p), sz) == 0
+    bufs, archive, junk_a, junk_b = ptrs[:k_slots], ptrs[k_slots], ptrs[k_slots + 1], ptrs[k_slots + 2]
+    consumer = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(consumer)) == 0
+    try:
+        with abi.Context() as ctx:
+            ctx.upload_scene(scene)
+            want = [ctx.render(scene.frame(time=t)) for t in times]
+            assert not np.array_equal(want[0], want[k_slots])
+            with pytest.raises(abi.PtError) as e:
+                ctx.stream_wait(0, consumer.value)          # nothing submitted to the slot
+            assert e.value.code == abi.PT_ERR_NOT_READY
+            for i, t in enumerate(times):
+                s = i % k_slots
+                if i >= k_slots:
+                    ctx.wait(s)                                  # (frame i - K is long done; its consumer may not be)
+                ctx.slot_wait_for(s, consumer.value)           # frame i overwrites what the consumer of frame i - K reads
+                ctx.submit_device(scene.frame(time=t), s, bufs[s].value)
+                ctx.stream_wait(s, consumer.value)
+                for _ in range(4):                              # the consumer is slow: about a millisecond before it reads
+                    assert hip.hipMemcpyAsync(junk_b, junk_a, junk_bytes, D2D, consumer) == 0
+                assert hip.hipMemcpyAsync(C.c_void_p(archive.value + i * nbytes), bufs[s], nbytes, D2D, consumer) == 0
+            for s in range(k_slots):
+                ctx.wait(s)
+            assert hip.hipStreamSynchronize(consumer) == 0
+            got = np.empty((n_frames, scene.height, scene.width, 4), np.float32)
+            assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), archive, got.nbytes, D2H) == 0
+            for i in range(n_frames):
+                assert np.array_equal(got[i].view(np.uint32), want[i].view(np.uint32)), f"frame {i}"
+    finally:
+        hip.hipStreamDestroy(consumer)
+        for p in ptrs:
+            hip.hipFree(p)

@@ -50,7 +50,7 @@ def test_struct_fields_are_in_header_order():
 def test_functions_have_the_header_arity():
     decls = dict(re.findall(r"pub fn (pt_\w+)\((.*?)\) -> ", RUST, re.S))
     for fn in ("pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_upload_materials", "pt_upload_objects",
-               "pt_render", "pt_render_device", "pt_render_device_noalloc", "pt_render_submit", "pt_render_submit_device", "pt_render_wait", "pt_host_alloc", "pt_host_free", "pt_query", "pt_read_aux", "pt_device_info",
+               "pt_render", "pt_render_device", "pt_render_device_noalloc", "pt_render_submit", "pt_render_submit_device", "pt_render_wait", "pt_render_stream_wait", "pt_render_slot_wait_for", "pt_host_alloc", "pt_host_free", "pt_query", "pt_read_aux", "pt_device_info",
                "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_upload_meshes", "pt_multi_upload_materials",
                "pt_multi_upload_objects", "pt_multi_render", "pt_multi_context", "pt_multi_rccl_version"):
         assert fn in decls, fn
