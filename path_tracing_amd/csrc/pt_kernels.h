@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
             if (__any(st == PT_ST_TRACE)) {
                 const bool tracing = st == PT_ST_TRACE;
                 const WideRay wr = make_wide_ray(world_slab_ray(rpos, rdir));
-                wide_walk_resume<STATS, PT_BURST_TLAS>([&](uint32_t r) { return tlas_node_at(sc, r); }, wr, wb.t, stk, ws, pp.walk_quota, cnt,
+                wide_walk_resume<STATS, PT_BURST_TLAS>([&](uint32_t r, uint4& q0, uint4& q1, uint4& q2, uint4& q3) { tlas_fetch(sc, r, q0, q1, q2, q3); }, wr, wb.t, stk, ws, pp.walk_quota, cnt,
                                                        [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, rpos, rdir, wb, stk, sp, cnt); });
                 if (tracing && ws.node == PT_WALK_DONE) {
                     nrays++;

@@ -66,19 +66,24 @@ struct SpillStack {
     uint32_t* overflow;  // this lane's column: entry k at overflow[k * stride]
     int lds_levels;
     uint32_t stride;
+    // (The address spaces are spelled out: given two branches that access memory through generic pointers, the compiler
+    // merges them into one flat access through a chosen pointer, which takes a slot in the LDS and in the vector-memory
+    // queue whichever memory the lane touches.)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(1))) uint32_t glb_u32;
     PT_DEV void put(int level, uint32_t v) {
-        if (level < lds_levels) base[level * 64] = v;
-        else overflow[(size_t)(level - lds_levels) * stride] = v;
+        if (level < lds_levels) ((lds_u32*)base)[level * 64] = v;
+        else ((glb_u32*)overflow)[(size_t)(level - lds_levels) * stride] = v;
     }
     PT_DEV uint32_t get(int level) const {
-        if (level < lds_levels) return base[level * 64];
-        return overflow[(size_t)(level - lds_levels) * stride];
+        if (level < lds_levels) return ((const lds_u32*)base)[level * 64];
+        return ((const glb_u32*)overflow)[(size_t)(level - lds_levels) * stride];
     }
     // Wave-uniform: no lane of the wave touches a level at or above `top` that lies outside LDS, so the plain LDS
     // accessors below may be used (the usual case; the per-access choice above costs a dozen instructions each time).
     PT_DEV bool all_in_lds(int top) const { return !__any(top > lds_levels); }
-    PT_DEV void put_lds(int level, uint32_t v) { base[level * 64] = v; }
-    PT_DEV uint32_t get_lds(int level) const { return base[level * 64]; }
+    PT_DEV void put_lds(int level, uint32_t v) { ((lds_u32*)base)[level * 64] = v; }
+    PT_DEV uint32_t get_lds(int level) const { return ((const lds_u32*)base)[level * 64]; }
 };
 
 PT_DEV bool candidate_wins(float t, uint32_t obj, uint32_t tri, const Best& b, uint32_t tie_lowest) {
@@ -285,18 +290,22 @@ PT_DEV uint32_t wide_visit(const uint4 q0, const uint4 q1, const uint4 q2, const
 #ifndef PT_BURST_TLAS
 #define PT_BURST_TLAS 8
 #endif
-// `node_at(ref)` gives the address of a node as a pointer to its four 16-byte parts. `tmax` is read through the
+// `fetch(ref, q0, q1, q2, q3)` reads the four 16-byte parts of a node. `tmax` is read through the
 // reference every time, so leaves that shorten the ray tighten the culling at once. `leaf(ref, sp)` gets the child
 // reference without PT_LEAF_BIT.
+PT_DEV void node_parts(const WNode* n, uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
+    const uint4* N = reinterpret_cast<const uint4*>(n);
+    q0 = N[0]; q1 = N[1]; q2 = N[2]; q3 = N[3];
+}
 template <bool STATS, int BURST, class NodeFn, class LeafFn, class Stk>
-PT_DEV void wide_walk(NodeFn node_at, uint32_t root, const WideRay& wr, const float& tmax, Stk stk, int sp0, bool active,
+PT_DEV void wide_walk(NodeFn fetch, uint32_t root, const WideRay& wr, const float& tmax, Stk stk, int sp0, bool active,
                       LaneCounters& cnt, LeafFn leaf) {
     uint32_t node = active ? root : PT_WALK_DONE;
     int sp = sp0;
     while (__any(node != PT_WALK_DONE)) {
         for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
-            const uint4* N = node_at(node);
-            const uint4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
+            uint4 q0, q1, q2, q3;
+            fetch(node, q0, q1, q2, q3);
             node = wide_visit<STATS, Stk>(q0, q1, q2, q3, wr, tmax, stk, sp, sp0, cnt);
         }
         if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
@@ -315,7 +324,7 @@ struct WalkState {
     int sp;
 };
 template <bool STATS, int BURST, class NodeFn, class LeafFn, class Stk>
-PT_DEV void wide_walk_resume(NodeFn node_at, const WideRay& wr, const float& tmax, Stk stk, WalkState& ws, uint32_t quota,
+PT_DEV void wide_walk_resume(NodeFn fetch, const WideRay& wr, const float& tmax, Stk stk, WalkState& ws, uint32_t quota,
                              LaneCounters& cnt, LeafFn leaf) {
     uint32_t node = ws.node;
     int sp = ws.sp;
@@ -326,8 +335,8 @@ PT_DEV void wide_walk_resume(NodeFn node_at, const WideRay& wr, const float& tma
         if (still <= stop_at) break;
         for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
             PT_COUNT(cnt, 8); PT_COUNT_LANES(cnt, 13, true);
-            const uint4* N = node_at(node);
-            const uint4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
+            uint4 q0, q1, q2, q3;
+            fetch(node, q0, q1, q2, q3);
             node = wide_visit<STATS, Stk>(q0, q1, q2, q3, wr, tmax, stk, sp, 0, cnt);
         }
         if (node != PT_WALK_DONE && (node & PT_LEAF_BIT)) {
@@ -385,7 +394,7 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
             const WNode* nodes = sc.blas_nodes;
             const DTri* tris = sc.tris + tri_first;
             const uint32_t* ids = sc.tri_ids + tri_first;
-            wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r) { return reinterpret_cast<const uint4*>(nodes + r); }, root, wr, best.t, stk, sp0, true, cnt,
+            wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r, uint4& q0, uint4& q1, uint4& q2, uint4& q3) { node_parts(nodes + r, q0, q1, q2, q3); }, root, wr, best.t, stk, sp0, true, cnt,
                                             [&](uint32_t leaf, int) {
                 const uint32_t pos = leaf & PT_WLEAF_POS_MASK, n = (leaf >> PT_WLEAF_COUNT_SHIFT) + 1u;
                 // (one triangle at a time here: the records are in LDS, and two in flight cost this variant registers)
@@ -439,7 +448,7 @@ PT_DEV void object_test(const SceneView& sc, uint32_t obj, v3 ro, v3 rd, Best& b
                 } else {
                     const WideRay wr = make_wide_ray(sr);
                     auto walk = [&](const WNode* nodes, const DTri* tris, const uint32_t* ids) {
-                        wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r) { return reinterpret_cast<const uint4*>(nodes + r); }, root, wr, cand.t, stk, sp0, true, cnt,
+                        wide_walk<STATS, PT_BURST_BLAS>([&](uint32_t r, uint4& q0, uint4& q1, uint4& q2, uint4& q3) { node_parts(nodes + r, q0, q1, q2, q3); }, root, wr, cand.t, stk, sp0, true, cnt,
                                                         [&](uint32_t leaf, int) {
                             const uint32_t pos = leaf & PT_WLEAF_POS_MASK, n = (leaf >> PT_WLEAF_COUNT_SHIFT) + 1u;
                             // (the first two triangles of a leaf are fetched together: one trip to memory instead of two)
@@ -726,10 +735,23 @@ PT_DEV void closest_hit_list_quad(const SceneView& sc, v3 ro, v3 rd, bool active
     }
 }
 
-// A TLAS node: from the copy of the tree's top levels in LDS when the kernel made one, else from global memory.
-PT_DEV const uint4* tlas_node_at(const SceneView& sc, uint32_t r) {
-    const WNode* n = (r < sc.tlas_top_n) ? sc.tlas_top + r : sc.tlas_nodes + r;
-    return reinterpret_cast<const uint4*>(n);
+// A TLAS node: from the copy of the tree's top levels in LDS when the kernel made one, else from global memory. Two
+// branches rather than one load through a chosen pointer: that one would be a flat load, which takes a slot in the LDS
+// and in the vector-memory queue for every lane, whichever memory the lane reads.
+// (The address spaces are spelled out: given two branches that load through generic pointers, the compiler merges them
+// into the one flat load again.)
+typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
+PT_DEV void tlas_fetch(const SceneView& sc, uint32_t r, uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
+    pt_u32x4 a, b, c, d;
+    if (r < sc.tlas_top_n) {
+        const __attribute__((address_space(3))) pt_u32x4* N = (const __attribute__((address_space(3))) pt_u32x4*)(sc.tlas_top + r);
+        a = N[0]; b = N[1]; c = N[2]; d = N[3];
+    } else {
+        const __attribute__((address_space(1))) pt_u32x4* N = (const __attribute__((address_space(1))) pt_u32x4*)(sc.tlas_nodes + r);
+        a = N[0]; b = N[1]; c = N[2]; d = N[3];
+    }
+    q0 = make_uint4(a.x, a.y, a.z, a.w); q1 = make_uint4(b.x, b.y, b.z, b.w);
+    q2 = make_uint4(c.x, c.y, c.z, c.w); q3 = make_uint4(d.x, d.y, d.z, d.w);
 }
 
 // hit_all through the TLAS: each lane walks the object tree on its own.
@@ -737,7 +759,7 @@ template <bool STATS, class Stk>
 PT_DEV void closest_hit_tlas(const SceneView& sc, v3 ro, v3 rd, bool active, Best& best, Stk stk, LaneCounters& cnt) {
     if (sc.tlas_root == PT_NONE) return;
     const WideRay wr = make_wide_ray(world_slab_ray(ro, rd));
-    wide_walk<STATS, PT_BURST_TLAS>([&](uint32_t r) { return tlas_node_at(sc, r); }, sc.tlas_root, wr, best.t, stk, 0, active, cnt,
+    wide_walk<STATS, PT_BURST_TLAS>([&](uint32_t r, uint4& q0, uint4& q1, uint4& q2, uint4& q3) { tlas_fetch(sc, r, q0, q1, q2, q3); }, sc.tlas_root, wr, best.t, stk, 0, active, cnt,
                     [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, ro, rd, best, stk, sp, cnt); });
 }
 
