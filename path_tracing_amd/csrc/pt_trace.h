@@ -335,6 +335,10 @@ PT_DEV void wide_walk_resume(NodeFn fetch, const WideRay& wr, const float& tmax,
         if (still <= stop_at) break;
         for (int burst = 0; burst < BURST && node != PT_WALK_DONE && !(node & PT_LEAF_BIT); ++burst) {
             PT_COUNT(cnt, 8); PT_COUNT_LANES(cnt, 13, true);
+#ifdef PT_EXEC_COUNTS
+            // (debug build: node-visit iterations that run with at most 16 and at most 32 lanes)
+            { const uint32_t al_ = (uint32_t)__popcll(__ballot(1)); if (al_ <= 16u) PT_COUNT(cnt, 7); if (al_ <= 32u) PT_COUNT(cnt, 11); }
+#endif
             uint4 q0, q1, q2, q3;
             fetch(node, q0, q1, q2, q3);
             node = wide_visit<STATS, Stk>(q0, q1, q2, q3, wr, tmax, stk, sp, 0, cnt);

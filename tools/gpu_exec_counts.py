@@ -10,8 +10,9 @@ NAMES = ["shade loop pass", "step 1 (any lane)", "add_emitted (hit)", "next_samp
          "next_sample after scatter", "trace executed", "world box test (wave)", "object pass", "triangle loop iteration", "exact gate", "finalize",
          "TLAS: lanes in node visits | list: cycles in the box loop", "TLAS: lanes in leaf calls | list: cycles in candidate passes",
          "global tri loop: lanes inside | list: cycles in hit records"]
-# (TLAS scenes reuse three rows: "world box test" = node-visit iterations of the resumable walk, "object pass" = its leaf calls,
-#  "triangle loop iteration" = iterations of the global-memory triangle loop)
+# (TLAS scenes reuse five rows: "world box test" = node-visit iterations of the resumable walk, "object pass" = its leaf calls,
+#  "triangle loop iteration" = iterations of the global-memory triangle loop, "trace executed" / "exact gate" = node-visit
+#  iterations that ran with at most 16 / at most 32 lanes)
 for n in (sys.argv[1:] or ["boxes"]):
     cfg, kw = SCENES[n]
     scene = scenes.CONFIGS[cfg](**kw)
