@@ -1,0 +1,186 @@
+"""Seeded random scenes through the C ABI against the CPU restatement, bit for bit.
+
+The hand-made scenes of test_gpu_parity.py each aim at one mechanism; these aim at none. Every scene draws its meshes
+(triangle soups, fans, bumpy sheets, with degenerate and duplicated triangles mixed in), its instance transforms
+(rotation, non-uniform and negative scale, shear, tiny and large instances), its materials (roughness inside and outside
+[0, 1], black and bright albedo, emitters, textures of 1-4 channels and non-square sizes in every texture role), its
+camera and sky from a seeded generator. Object counts fall on both sides of every organisation the library chooses
+between (scene staged in LDS, object list, object list with a BLAS in LDS, TLAS), triangle counts on both sides of the
+BLAS threshold. What must agree with the restatement (reference src/raytrace.wgsl:207-277, src/query.wgsl:55-147):
+primary object and triangle ids, the primary distance's bits, every pixel's ray count, every bit of the image.
+"""
+import numpy as np
+import pytest
+
+from path_tracing_amd import abi, scenes
+from tests.oracle_lib import oracle_render
+
+pytestmark = pytest.mark.gpu
+
+
+def _soup(g, n_tris, spread, size):
+    """Unconnected triangles around the origin."""
+    c = g.uniform(-spread, spread, (n_tris, 1, 3))
+    p = c + g.normal(0.0, size, (n_tris, 3, 3))
+    pos = p.reshape(-1, 3)
+    nrm = g.normal(0.0, 1.0, pos.shape)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-6)
+    uv = g.uniform(-0.25, 1.25, (len(pos), 2))          # (outside [0, 1] too: sample_texture neither wraps nor clamps)
+    return pos, nrm, uv, np.arange(3 * n_tris)
+
+
+def _sheet(g, n, amp):
+    """(n x n)-cell height field over [-1, 1]^2, both windings of its diagonal split in use."""
+    x = np.linspace(-1.0, 1.0, n + 1)
+    xx, zz = np.meshgrid(x, x, indexing="ij")
+    yy = amp * g.normal(0.0, 1.0, xx.shape)
+    pos = np.stack([xx, yy, zz], axis=-1).reshape(-1, 3)
+    nrm = np.tile(np.array([0.0, 1.0, 0.0]), (len(pos), 1))
+    uv = np.stack([(xx + 1) / 2, (zz + 1) / 2], axis=-1).reshape(-1, 2)
+    idx = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
+            idx += [a, d, b, b, d, c] if (i + j) % 2 else [a, d, c, a, c, b]
+    return pos, nrm, uv, np.array(idx)
+
+
+def _spoil(g, pos, idx):
+    """A few degenerate triangles (two corners equal, three corners in line) and one triangle listed twice."""
+    idx = np.array(idx).reshape(-1, 3).copy()
+    n = len(idx)
+    if n >= 6:
+        k = g.integers(0, n, 3)
+        idx[k[0], 1] = idx[k[0], 0]                                   # zero area: two corners are one vertex
+        idx[k[1]] = idx[k[2]]                                          # the same triangle twice (equal distances: the tie rule)
+        pos = pos.copy()
+        a, b, c = idx[g.integers(0, n)]
+        pos[c] = 0.5 * (pos[a] + pos[b])                               # three corners (nearly) in line
+    return pos, idx.reshape(-1)
+
+
+def _transform(g, scale_lo, scale_hi, extent):
+    q = g.normal(size=4)
+    q /= np.linalg.norm(q)
+    m = scenes.translation(*g.uniform(-extent, extent, 3)) @ scenes.quat_to_mat(q)
+    s = g.uniform(scale_lo, scale_hi, 3)
+    if g.uniform() < 0.25:
+        s[g.integers(0, 3)] *= -1.0                                    # a mirrored instance: every winding flips
+    m = m @ scenes.scaling(*s)
+    if g.uniform() < 0.25:
+        sh = np.eye(4)
+        sh[0, 1] = g.uniform(-0.5, 0.5)                                # shear
+        m = m @ sh
+    return m
+
+
+def random_scene(seed, n_objects, width=48, height=32, samples=4, bounces=6):
+    g = np.random.Generator(np.random.PCG64(seed))
+    b = scenes.SceneBuilder()
+    texs = []
+    for ch in (1, 2, 3, 4):
+        w, h = int(g.integers(2, 9)), int(g.integers(2, 9))
+        texs.append(b.add_texture(g.uniform(0.0, 1.0, w * h * ch), w, h, ch))
+    meshes = []
+    for kind in range(int(g.integers(3, 7))):
+        r = g.uniform()
+        if r < 0.35:
+            pos, nrm, uv, idx = _soup(g, int(g.integers(1, 40)), g.uniform(0.3, 1.0), g.uniform(0.1, 0.5))
+        elif r < 0.7:
+            pos, nrm, uv, idx = _sheet(g, int(g.integers(2, 14)), g.uniform(0.0, 0.15))
+        elif r < 0.85:
+            pos, nrm, uv, idx = scenes.cube_mesh(float(g.uniform(0.5, 1.5)))
+            pos, nrm, uv, idx = np.asarray(pos, np.float64), np.asarray(nrm, np.float64), np.asarray(uv, np.float64), np.asarray(idx)
+        else:
+            pos, nrm, uv, idx = scenes.plane_mesh((0, 1, 0), float(g.uniform(0.5, 2.0)))
+            pos, nrm, uv, idx = np.asarray(pos, np.float64), np.asarray(nrm, np.float64), np.asarray(uv, np.float64), np.asarray(idx)
+        if g.uniform() < 0.5:
+            pos, idx = _spoil(g, np.asarray(pos, np.float64), idx)
+        meshes.append(b.add_mesh(pos, nrm, uv, idx))
+    mats = []
+    for _ in range(int(g.integers(3, 9))):
+        kw = dict(albedo=tuple(g.uniform(0.0, 1.0, 3)), roughness=float(g.choice([0.0, 0.089, 0.3, 0.5, 1.0, 1.7, -0.2])))
+        r = g.uniform()
+        if r < 0.15:
+            kw.update(albedo=(0, 0, 0), emissive=tuple(g.uniform(0.5, 5.0, 3)))
+        elif r < 0.25:
+            kw.update(emissive=tuple(g.uniform(0.0, 1.0, 3)))
+        for role in ("albedo_texture", "emissive_texture", "metallic_roughness_texture", "normal_map_texture"):
+            if g.uniform() < 0.2:
+                kw[role] = texs[int(g.integers(0, len(texs)))]
+        mats.append(b.add_material(**kw))
+    extent = 1.5 + 0.25 * np.sqrt(n_objects)
+    centre = np.zeros(3)
+    for k in range(n_objects):
+        tiny = g.uniform() < 0.1
+        m = _transform(g, 0.02 if tiny else 0.3, 0.06 if tiny else 1.6, extent)
+        centre += m[:3, 3] / n_objects
+        b.add_object(meshes[int(g.integers(0, len(meshes)))], mats[int(g.integers(0, len(mats)))], m)
+    eye = g.normal(size=3)
+    eye = centre + eye * (1.4 * extent) / np.linalg.norm(eye)
+    cam = scenes.Camera(tuple(eye), tuple(centre + g.uniform(-0.3, 0.3, 3)))
+    return b.build(f"random{seed}", cam, sky_color=tuple(g.uniform(0.0, 0.6, 3)), width=width, height=height, samples=samples, bounces=bounces)
+
+
+# (objects: 1 .. 12 object list or staged in LDS, 13 and up TLAS, more than 32 never staged)
+CASES = [(214, 1), (213, 2), (201, 1), (103, 5), (104, 9), (105, 12), (106, 13), (107, 20), (108, 33), (109, 70), (110, 200),
+         (111, 7), (112, 16), (113, 3), (114, 40)]
+# bigger frames with enough samples for the sample sweeps, split chunks and cost hints of k_paths to come into play
+BIG_CASES = [(301, 8, dict(width=160, height=96, samples=16, bounces=10)), (302, 30, dict(width=128, height=80, samples=16, bounces=6)),
+             (305, 4, dict(width=96, height=64, samples=32, bounces=10)), (304, 11, dict(width=200, height=120, samples=16, bounces=8))]
+
+
+@pytest.mark.parametrize("seed,n_objects", CASES)
+def test_random_scene_against_the_oracle(seed, n_objects):
+    scene = random_scene(seed, n_objects)
+    for time in (0.0, 2.5):
+        frame = scene.frame(time=time)
+        ref = oracle_render(scene, frame)
+        for accel in (abi.PT_ACCEL_AUTO, abi.PT_ACCEL_BVH, abi.PT_ACCEL_BRUTE):
+            with abi.Context(accel=accel) as ctx:
+                ctx.upload_scene(scene)
+                img = ctx.render(frame)
+                assert ctx.check_accel()["errors"] == 0
+                what = f"seed {seed}, {n_objects} objects, time {time}, accel {accel}"
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_OBJECT), ref["primary_object"]), what
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID), ref["primary_flat_id"]), what
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_T).view(np.uint32), ref["primary_t"].view(np.uint32)), what
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), ref["ray_count"]), what
+                assert np.array_equal(img.view(np.uint32), ref["image"].view(np.uint32)), what
+                # the same frame again (schedule hints from the first one now in use) and on a slot of the context
+                again = ctx.render(frame)
+                assert np.array_equal(again.view(np.uint32), img.view(np.uint32)), what + " (second frame)"
+                buf = ctx.host_array(img.shape, np.float32)
+                ctx.submit(frame, 0, buf)
+                ctx.wait(0)
+                assert np.array_equal(buf.view(np.uint32), img.view(np.uint32)), what + " (slot)"
+
+
+@pytest.mark.parametrize("seed,n_objects,kw", BIG_CASES)
+def test_bigger_random_frames_against_the_oracle(seed, n_objects, kw):
+    scene = random_scene(seed, n_objects, **kw)
+    frame = scene.frame(time=1.5)
+    ref = oracle_render(scene, frame)
+    assert int((ref["primary_object"] != abi.PT_U32_MAX).sum()) > 200
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        bufs = [ctx.host_array(ref["image"].shape, np.float32) for _ in range(3)]
+        for rep in range(3):           # the second and third pass run with the first one's ray counts as cost hints
+            for s in range(3):
+                ctx.submit(frame, s, bufs[s])
+            for s in range(3):
+                ctx.wait(s)
+                assert np.array_equal(bufs[s].view(np.uint32), ref["image"].view(np.uint32)), f"seed {seed}, pass {rep}, slot {s}"
+                assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), ref["ray_count"]), f"seed {seed}, pass {rep}, slot {s}"
+        assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID), ref["primary_flat_id"])
+        assert ctx.check_accel()["errors"] == 0
+
+
+def test_random_scenes_hit_something():
+    """(The cases above would pass trivially on pictures of the sky.)"""
+    seen = 0
+    for seed, n in CASES:
+        scene = random_scene(seed, n)
+        ref = oracle_render(scene, scene.frame())
+        seen += int((ref["primary_object"] != abi.PT_U32_MAX).sum())
+    assert seen > 0.1 * len(CASES) * 48 * 32
