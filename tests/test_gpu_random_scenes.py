@@ -74,7 +74,7 @@ def _transform(g, scale_lo, scale_hi, extent):
     return m
 
 
-def random_scene(seed, n_objects, width=48, height=32, samples=4, bounces=6):
+def random_scene(seed, n_objects, width=48, height=32, samples=4, bounces=6, world_scale=1.0):
     g = np.random.Generator(np.random.PCG64(seed))
     b = scenes.SceneBuilder()
     texs = []
@@ -113,12 +113,12 @@ def random_scene(seed, n_objects, width=48, height=32, samples=4, bounces=6):
     centre = np.zeros(3)
     for k in range(n_objects):
         tiny = g.uniform() < 0.1
-        m = _transform(g, 0.02 if tiny else 0.3, 0.06 if tiny else 1.6, extent)
+        m = scenes.scaling(world_scale, world_scale, world_scale) @ _transform(g, 0.02 if tiny else 0.3, 0.06 if tiny else 1.6, extent)
         centre += m[:3, 3] / n_objects
         b.add_object(meshes[int(g.integers(0, len(meshes)))], mats[int(g.integers(0, len(mats)))], m)
     eye = g.normal(size=3)
-    eye = centre + eye * (1.4 * extent) / np.linalg.norm(eye)
-    cam = scenes.Camera(tuple(eye), tuple(centre + g.uniform(-0.3, 0.3, 3)))
+    eye = centre + eye * (1.4 * extent * world_scale) / np.linalg.norm(eye)
+    cam = scenes.Camera(tuple(eye), tuple(centre + world_scale * g.uniform(-0.3, 0.3, 3)))
     return b.build(f"random{seed}", cam, sky_color=tuple(g.uniform(0.0, 0.6, 3)), width=width, height=height, samples=samples, bounces=bounces)
 
 
@@ -174,6 +174,27 @@ def test_bigger_random_frames_against_the_oracle(seed, n_objects, kw):
                 assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), ref["ray_count"]), f"seed {seed}, pass {rep}, slot {s}"
         assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID), ref["primary_flat_id"])
         assert ctx.check_accel()["errors"] == 0
+
+
+@pytest.mark.parametrize("world_scale", [1.0e-2, 30.0, 1.0e2, 1.0e3])
+@pytest.mark.parametrize("seed,n_objects", [(104, 9), (107, 20), (109, 70)])
+def test_random_scenes_at_other_scales(seed, n_objects, world_scale):
+    """The same scenes blown up and shrunk (the reference's T_MIN, its 0.001 ray offset and its maximum distance of 1000
+    are absolute, src/math.wgsl:3-6, src/raytrace.wgsl:229,262, so these are different pictures): the culling pads of the
+    library are relative to the coordinates and must hold at any size; beyond 1000 units nothing is hit."""
+    scene = random_scene(seed, n_objects, world_scale=world_scale)
+    frame = scene.frame(time=0.5)
+    ref = oracle_render(scene, frame)
+    for accel in (abi.PT_ACCEL_AUTO, abi.PT_ACCEL_BVH):
+        with abi.Context(accel=accel) as ctx:
+            ctx.upload_scene(scene)
+            img = ctx.render(frame)
+            what = f"seed {seed}, scale {world_scale}, accel {accel}"
+            assert ctx.check_accel()["errors"] == 0
+            assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID), ref["primary_flat_id"]), what
+            assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_T).view(np.uint32), ref["primary_t"].view(np.uint32)), what
+            assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), ref["ray_count"]), what
+            assert np.array_equal(img.view(np.uint32), ref["image"].view(np.uint32)), what
 
 
 def test_random_scenes_hit_something():
