@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from path_tracing_amd import abi, scenes
-from tests.oracle_lib import oracle_render
+from tests.oracle_lib import oracle_query, oracle_render
 
 pytestmark = pytest.mark.gpu
 
@@ -195,6 +195,53 @@ def test_random_scenes_at_other_scales(seed, n_objects, world_scale):
             assert np.array_equal(ctx.read_aux(abi.PT_AUX_PRIMARY_T).view(np.uint32), ref["primary_t"].view(np.uint32)), what
             assert np.array_equal(ctx.read_aux(abi.PT_AUX_RAY_COUNT), ref["ray_count"]), what
             assert np.array_equal(img.view(np.uint32), ref["image"].view(np.uint32)), what
+
+
+@pytest.mark.parametrize("seed,n_objects", [(105, 12), (107, 20), (110, 200), (111, 7)])
+@pytest.mark.parametrize("tie", [abi.PT_TIE_REFERENCE, abi.PT_TIE_LOWEST])
+def test_random_rays_through_random_scenes(seed, n_objects, tie):
+    """hit_all on its own (reference src/query.wgsl:55-64): rays from inside and outside the scene, unit and non-unit
+    directions (a mix(reflected, diffuse) direction is not renormalised, src/raytrace.wgsl:165), directions with zero
+    components, origins on vertices of the meshes; both tie rules (the duplicated triangles of the scenes make ties)."""
+    scene = random_scene(seed, n_objects)
+    g = np.random.Generator(np.random.PCG64(seed + 7000))
+    n = 6144
+    extent = 1.5 + 0.25 * np.sqrt(n_objects)
+    rays = np.zeros(n, dtype=abi.RAY_DT)
+    rays["pos"] = g.uniform(-1.5 * extent, 1.5 * extent, (n, 3)).astype(np.float32)
+    d = g.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[: n // 4] *= g.uniform(0.05, 20.0, (n // 4, 1))         # non-unit directions: t scales with their length
+    rays["dir"] = d.astype(np.float32)
+    rays["dir"][1000:1100, 0] = 0.0
+    rays["dir"][1100:1200, 1] = 0.0
+    rays["dir"][1200:1300, 2] = 0.0
+    rays["dir"][1300:1340, :2] = 0.0                            # along +-z exactly
+    # origins on transformed mesh vertices (distance 0 to a triangle corner), aimed at random
+    l2w = scene.objects["local_to_world"].reshape(-1, 4, 4).transpose(0, 2, 1).astype(np.float64)
+    for k in range(2000, 2400):
+        o = int(g.integers(0, scene.objects.size))
+        me = scene.meshes[int(scene.objects["mesh"][o])]
+        v = scene.vertices["position"][int(me["vhead"]) + int(g.integers(0, 3))].astype(np.float64)
+        rays["pos"][k] = (l2w[o] @ np.append(v, 1.0))[:3].astype(np.float32)
+    # (the restatement has the reference's rule only; with the other rule the exhaustive loop is the yardstick, and the two
+    #  must agree wherever distances are not tied)
+    want = oracle_query(scene, rays)
+    if tie == abi.PT_TIE_LOWEST:
+        with abi.Context(accel=abi.PT_ACCEL_BRUTE, tie_rule=tie) as ctx:
+            ctx.upload_scene(scene)
+            lowest = ctx.query(rays)
+        assert np.array_equal(lowest["t"].view(np.uint32), want["t"].view(np.uint32))
+        differ = lowest["flat_id"] != want["flat_id"]
+        assert np.all(lowest["flat_id"][differ] < want["flat_id"][differ])
+        want = lowest
+    for accel in (abi.PT_ACCEL_AUTO, abi.PT_ACCEL_BVH, abi.PT_ACCEL_BRUTE):
+        with abi.Context(accel=accel, tie_rule=tie) as ctx:
+            ctx.upload_scene(scene)
+            got = ctx.query(rays)
+        bad = np.nonzero((got.view(np.uint32).reshape(n, -1) != want.view(np.uint32).reshape(n, -1)).any(axis=1))[0]
+        assert bad.size == 0, f"seed {seed}, accel {accel}, tie {tie}: {bad.size} rays differ, first {bad[:8]}"
+    assert (want["object"] != abi.PT_U32_MAX).sum() > 200
 
 
 def test_random_scenes_hit_something():
