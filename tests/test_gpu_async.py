@@ -260,3 +260,17 @@ def test_gpu_side_ordering_of_a_slot_against_a_consumer_stream():
         hip.hipStreamDestroy(consumer)
         for p in ptrs:
             hip.hipFree(p)
+
+
+@pytest.mark.parametrize("name,iterations,seed", [("inst", 500, 11), ("boxes", 500, 12)])
+def test_random_order_of_uploads_frames_and_queries(name, iterations, seed):
+    """tools/gpu_soak.py: object uploads (five versions of the array), frames on four slots, synchronous frames and ray
+    queries in a seeded random order on ONE context; every finished image must be the one a fresh context renders for the
+    same object array and time (src/extract.rs:297-346 rewrites the objects every frame, src/shader.rs:121-213 draws)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    tool = Path(__file__).resolve().parent.parent / "tools" / "gpu_soak.py"
+    r = subprocess.run([sys.executable, str(tool), name, str(iterations), str(seed)], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "ok:" in r.stdout
