@@ -26,6 +26,7 @@ constexpr uint32_t kBlasMinTris = 16;   // PT_ACCEL_AUTO: meshes with more trian
 constexpr uint32_t kTlasMinObjects = 12; // PT_ACCEL_AUTO: scenes with more objects than this get a TLAS
 constexpr uint32_t kMaxStackDepth = 96;
 constexpr uint32_t kBlasNeedMaxSah = 48;    // stack entries a surface-area BLAS may need before the mesh is built in Morton order instead
+constexpr uint32_t kTlasSettledUploads = 8;        // uploads with one object count after which a scene counts as settled (see rebuild_objects)
 constexpr uint32_t kSahHostMaxTris = 1u << 17;     // meshes up to this many triangles get their BLAS from the host-side builder
 constexpr uint32_t kCollapseOneGroupMax = 4096;   // primitives up to which one workgroup makes the whole wide tree
 constexpr uint32_t kTlasMaxRefits = 15;  // object uploads that may refit the TLAS before it is built afresh  // LDS: 4 waves * depth * 256 B per workgroup
@@ -210,6 +211,10 @@ struct pt_ctx {
     uint32_t lds_per_cu = 160 * 1024;
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
     uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
+    bool tlas_topology_sah = false;   // ... and whether the surface-area builder made it
+    uint32_t tlas_last_n = 0;         // object count of the previous upload
+    uint32_t tlas_stable_uploads = 0; // uploads in a row with that count (the count before it lasted tlas_stable_before)
+    uint32_t tlas_stable_before = 0;
     uint32_t tlas_refits = 0;     // refits since that build
     bool cost_hints = true;       // order the path list by the previous frame's per-pixel ray counts when they apply
     uint32_t split_fraction[2] = {PT_SPLIT_FRACTION_ALONE, PT_SPLIT_FRACTION};   // at most 1/this of the chunks are handed out in parts {frame alone on the device, other frames running}
@@ -1017,7 +1022,15 @@ int rebuild_objects(pt_ctx* ctx, uint32_t target) {
             // costs traversal steps, so a fresh build is made every kTlasMaxRefits updates. The 4-wide tree keeps its
             // topology too: its nodes (copied from the version before when this one has buffers of its own) take the new
             // boxes from the binary nodes they were made from.
-            if (ctx->allow_refit && ctx->tlas_built_n == n && ctx->tlas_refits < kTlasMaxRefits && kept[0] > 0) {
+            // The surface-area builder runs on the host and takes tens of milliseconds for tens of thousands of objects: worth
+            // it for a scene that arrives and then stays (first upload, or a new count after the old one had lasted), not for
+            // one whose count changes every few frames, which gets the device builder; once such a scene has kept its count
+            // for kTlasSettledUploads uploads, its tree is built once more, by surface area.
+            if (n == ctx->tlas_last_n) ctx->tlas_stable_uploads++;
+            else { ctx->tlas_stable_before = ctx->tlas_stable_uploads; ctx->tlas_stable_uploads = 0; ctx->tlas_last_n = n; }
+            const bool sah_possible = ctx->tlas_sah && n <= kSahHostMaxTris;
+            const bool upgrade = sah_possible && ctx->tlas_built_n == n && !ctx->tlas_topology_sah && ctx->tlas_stable_uploads >= kTlasSettledUploads;
+            if (ctx->allow_refit && ctx->tlas_built_n == n && ctx->tlas_refits < kTlasMaxRefits && kept[0] > 0 && !upgrade) {
                 PT_HIP(ctx, ctx->t_arrive.ensure(nb));
                 PT_HIP(ctx, hipMemsetAsync(ctx->t_arrive.p, 0, nb, s));
                 k_fit<<<div_up(n, 256), 256, 0, s>>>(T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, ctx->d_tlas_order.as<uint32_t>(), n,
@@ -1037,7 +1050,9 @@ int rebuild_objects(pt_ctx* ctx, uint32_t target) {
                 // A scene that arrives (first upload, or another number of objects) gets the surface-area tree from the host when
                 // it is of moderate size: it is walked by every ray of every frame until the objects change, and refits keep its
                 // topology. The periodic fresh build of a scene whose objects keep moving uses the fast device builder.
-                const bool sah = ctx->tlas_sah && n <= kSahHostMaxTris && (ctx->tlas_built_n != n);
+                const bool arrived = ctx->tlas_built_n != n && (ctx->tlas_built_n == 0 || ctx->tlas_stable_before >= kTlasSettledUploads);
+                const bool sah = sah_possible && (arrived || upgrade);
+                ctx->tlas_topology_sah = sah;
                 int rc = sah ? build_sah_host(ctx, T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false)
                              : build_lbvh(ctx, T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false);
                 if (rc != PT_OK) return rc;

@@ -3,6 +3,8 @@ and needle-shaped meshes, very small and very large instances, far-away origins,
 TLAS. The culling may never change a result, so every case compares the accelerated path with the exhaustive loop of the
 same library bit for bit (images, primary hits, ray counts, and closest-hit queries for random rays) and runs the
 device-side tree checks. (The exhaustive loop itself is pinned against the CPU restatement in test_gpu_parity.py.)"""
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -165,3 +167,48 @@ def test_geometrically_spaced_triangles_get_a_tree_the_stack_can_hold(capfd, mon
         assert np.array_equal(prim, ctx.read_aux(abi.PT_AUX_PRIMARY_FLAT_ID))
     assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
     assert (prim != abi.PT_U32_MAX).sum() > 20
+
+
+def _shifted(objs, dy):
+    """The objects moved by dy along the world's y axis (world_to_local kept the inverse of local_to_world)."""
+    o = objs.copy()
+    w2l = o["world_to_local"].astype(np.float64)
+    o["local_to_world"][:, 13] = (o["local_to_world"][:, 13].astype(np.float64) + dy).astype(np.float32)
+    o["world_to_local"][:, 12:15] = (w2l[:, 12:15] - dy * w2l[:, 4:7]).astype(np.float32)
+    return o
+
+
+def test_tlas_builder_follows_how_settled_the_object_count_is():
+    """A scene that arrives and stays gets its TLAS from the host-side surface-area builder (tens of milliseconds for tens
+    of thousands of objects); one whose object count changes every frame must not pay that per frame and gets the device
+    builder, until the count has lasted for a while. Whatever the tree, the image is the one of a fresh context."""
+    full = scenes.instanced_boxes(n_objects=40000, width=96, height=64, samples=2, extent=30.0)
+    frame = full.frame()
+
+    def fresh(objs):
+        with abi.Context() as c:
+            c.upload_scene(dataclasses.replace(full, objects=objs))
+            return c.render(frame)
+
+    with abi.Context() as ctx:
+        ctx.upload_scene(full)
+        sah_ms = ctx.stats()["build_ms"]
+        assert np.array_equal(ctx.render(frame), fresh(full.objects))
+        churn = []
+        for k in (1, 2, 3, 4):
+            objs = full.objects[: full.objects.size - 50 * k]
+            ctx.upload_objects(objs)
+            churn.append(ctx.stats()["build_ms"])
+            if k in (1, 4):
+                assert np.array_equal(ctx.render(frame), fresh(objs)), f"after dropping {50 * k} objects"
+        assert max(churn) < 0.5 * sah_ms, (sah_ms, churn)
+        # the count now stays: refits, then one more build, by surface area
+        settled = []
+        for k in range(12):
+            ctx.upload_objects(_shifted(objs, 0.01 * (k + 1)))
+            settled.append(ctx.stats()["build_ms"])
+        assert max(settled) > 0.5 * sah_ms, (sah_ms, settled)
+        assert sorted(settled)[-2] < 0.5 * sah_ms, (sah_ms, settled)       # ... once
+        last = _shifted(objs, 0.01 * 12)
+        assert np.array_equal(ctx.render(frame), fresh(last))
+        assert ctx.check_accel()["errors"] == 0
