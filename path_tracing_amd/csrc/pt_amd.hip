@@ -211,7 +211,7 @@ struct pt_ctx {
     uint32_t lds_per_cu = 160 * 1024;
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
     uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
-    bool tlas_topology_sah = false;   // ... and whether the surface-area builder made it
+    bool tlas_upgrade_pending = false;   // ... made by the device builder because the count kept changing: due for one surface-area build
     uint32_t tlas_last_n = 0;         // object count of the previous upload
     uint32_t tlas_stable_uploads = 0; // uploads in a row with that count (the count before it lasted tlas_stable_before)
     uint32_t tlas_stable_before = 0;
@@ -1029,7 +1029,7 @@ int rebuild_objects(pt_ctx* ctx, uint32_t target) {
             if (n == ctx->tlas_last_n) ctx->tlas_stable_uploads++;
             else { ctx->tlas_stable_before = ctx->tlas_stable_uploads; ctx->tlas_stable_uploads = 0; ctx->tlas_last_n = n; }
             const bool sah_possible = ctx->tlas_sah && n <= kSahHostMaxTris;
-            const bool upgrade = sah_possible && ctx->tlas_built_n == n && !ctx->tlas_topology_sah && ctx->tlas_stable_uploads >= kTlasSettledUploads;
+            const bool upgrade = sah_possible && ctx->tlas_built_n == n && ctx->tlas_upgrade_pending && ctx->tlas_stable_uploads >= kTlasSettledUploads;
             if (ctx->allow_refit && ctx->tlas_built_n == n && ctx->tlas_refits < kTlasMaxRefits && kept[0] > 0 && !upgrade) {
                 PT_HIP(ctx, ctx->t_arrive.ensure(nb));
                 PT_HIP(ctx, hipMemsetAsync(ctx->t_arrive.p, 0, nb, s));
@@ -1052,7 +1052,8 @@ int rebuild_objects(pt_ctx* ctx, uint32_t target) {
                 // topology. The periodic fresh build of a scene whose objects keep moving uses the fast device builder.
                 const bool arrived = ctx->tlas_built_n != n && (ctx->tlas_built_n == 0 || ctx->tlas_stable_before >= kTlasSettledUploads);
                 const bool sah = sah_possible && (arrived || upgrade);
-                ctx->tlas_topology_sah = sah;
+                if (sah) ctx->tlas_upgrade_pending = false;
+                else if (ctx->tlas_built_n != n) ctx->tlas_upgrade_pending = true;   // (not the periodic fresh build of moving objects)
                 int rc = sah ? build_sah_host(ctx, T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false)
                              : build_lbvh(ctx, T.d_obj_lo.as<float4>(), T.d_obj_hi.as<float4>(), 0, n, ctx->d_tlas_bnodes.as<BvhNode>(), 0, slot, false);
                 if (rc != PT_OK) return rc;
