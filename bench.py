@@ -23,7 +23,7 @@ scenes are static). The timed region of K steps is repeated (--repeats, fewer fo
 `value` and `ms_per_step` are the median repeat, the fastest one is reported beside it. More timings of the same K
 steps are reported: one frame at a time (one slot), with a camera that swings about the view target by up to 0.002 rad
 per frame (the schedule hints then come from a slightly different view), with the hints switched off (what the first
-frame after a cut gets), and what the plugin gets through the boundary as INTEGRATION.md shows it, image delivered to
+frame after a cut gets), and what a plugin that replaces RayTraceNode::run gets through the boundary, image delivered to
 page-locked host memory as binary16 each frame: synchronously (`ms_per_step_plugin_sync`: pt_render) and with frames in
 flight (`ms_per_step_plugin_async`: pt_render_submit / pt_render_wait); and the headline arrangement in a process that
 leaves HIP's hardware-queue count at its default (`ms_per_step_default_hw_queues`).
@@ -347,7 +347,7 @@ def main():
                         pass
 
     class PluginSync:
-        """What INTEGRATION.md's replacement of RayTraceNode::run does: one synchronous pt_render per frame, binary16
+        """What a drop-in replacement of RayTraceNode::run (reference src/shader.rs:121-213) does: one synchronous pt_render per frame, binary16
         image into page-locked host memory."""
 
         def __init__(self, c, host):
