@@ -446,6 +446,12 @@ int pt_device_info(pt_ctx* ctx, char* buf, size_t buf_bytes);
  * four lanes to a ray, 3 x 0}.
  * Copies at most out_bytes; *n_records = records available. Profiling aid, no counterpart in the reference. */
 int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n_records);
+/* Where a slot's frames stand, without waiting for anything (for a watchdog that finds a wait not returning):
+ * out[0] a frame is submitted, out[1] hipStreamQuery of the slot's stream (0: idle), out[2] frames enqueued so far; then for
+ * each of the slot's two frame records six words: pending, hipEventQuery of its end event, and from its device counters
+ * the entries of the path list, the queue head of k_paths, its waves that have left, the low word of its ray count.
+ * `n_out` >= 16 words. No counterpart in the reference. */
+int pt_debug_slot_state(pt_ctx* ctx, uint32_t slot, uint32_t* out, uint32_t n_out);
 
 /* Diagnostics: verifies on the device that every node box of the TLAS and of every
  * BLAS encloses what lies below it; *n_errors = number of violations found.

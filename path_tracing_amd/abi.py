@@ -112,7 +112,7 @@ assert C.sizeof(PtSettings) == 32 and C.sizeof(PtFrame) == 192 and C.sizeof(PtCo
 # every symbol include/pt_amd.h declares
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_upload_meshes", "pt_upload_materials",
            "pt_upload_objects", "pt_render", "pt_render_device", "pt_query", "pt_read_aux",
-           "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log", "pt_host_alloc", "pt_host_free",
+           "pt_set_stats_detail", "pt_get_stats", "pt_device_info", "pt_debug_check_accel", "pt_debug_wave_log", "pt_debug_slot_state", "pt_host_alloc", "pt_host_free",
            "pt_render_device_noalloc", "pt_render_submit", "pt_render_submit_device", "pt_render_wait",
            "pt_render_stream_wait", "pt_render_slot_wait_for",
            "pt_multi_create", "pt_multi_destroy", "pt_multi_last_error", "pt_multi_upload_meshes", "pt_multi_upload_materials",
@@ -164,6 +164,7 @@ def load_library():
     lib.pt_device_info.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.pt_debug_check_accel.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pt_debug_wave_log.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32)]
+    lib.pt_debug_slot_state.argtypes = [vp, u32, vp, u32]
     lib.pt_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.pt_host_free.argtypes = [vp, vp]
     lib.pt_multi_create.argtypes = [C.POINTER(PtMultiConfig), C.POINTER(vp)]
@@ -401,6 +402,12 @@ class Context:
         """pt_render_slot_wait_for: what is submitted to `slot` from now on starts when the work enqueued on `stream` so far
         is complete."""
         self._check(self._lib.pt_render_slot_wait_for(self._h, slot, C.c_void_p(stream) if stream else None))
+
+    def slot_state(self, slot: int) -> np.ndarray:
+        """pt_debug_slot_state: 16 words on where the slot's frames stand; waits for nothing."""
+        out = np.zeros(16, dtype=np.uint32)
+        self._check(self._lib.pt_debug_slot_state(self._h, slot, _ptr(out), out.size))
+        return out
 
     def query(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)

@@ -207,7 +207,7 @@ struct pt_ctx {
     bool k1_narrow = false;       // k_primary with four waves per workgroup even where sixteen fit (PT_AMD_K1_NARROW)
     int blocks_per_cu = 0;        // workgroups of k_paths per compute unit at most (PT_AMD_BLOCKS_PER_CU; 0: what fits)
     bool debug = false;           // PT_AMD_DEBUG: a line per frame on stderr
-    bool slot_priority = true;    // see lane_init
+    bool slot_priority = false;   // see lane_init
     uint32_t lds_per_cu = 160 * 1024;
     bool allow_refit = true;      // pt_upload_objects may refit the TLAS instead of rebuilding it
     uint32_t tlas_built_n = 0;    // object count the kept TLAS topology was built for (0: none kept)
@@ -891,10 +891,13 @@ hipError_t lane_init(pt_ctx* ctx, Lane& L, bool own_stream) {
     if (L.ready) return hipSuccess;
     hipError_t e = hipSuccess;
     if (own_stream) {
-        // A priority of its own kind: the runtime keeps the hardware queues of each priority apart, so the slots' streams
-        // do not have to share the few queues a process has by default (four) with its other streams (the null stream, the
-        // context's upload stream, the host application's own), which would make two slots run their frames one after
-        // the other. PT_AMD_SLOT_PRIORITY=0 creates them with the default priority.
+        // PT_AMD_SLOT_PRIORITY=1: a priority of its own kind. The runtime keeps the hardware queues of each priority apart, so
+        // the slots' streams then do not have to share the few queues a process has by default (four) with its other
+        // streams (the null stream, the context's upload stream, the host application's own), which would make two slots
+        // run their frames one after the other. Not the default: with more than four queues of that priority in use the
+        // scheduler swaps queues in and out, and k_paths -- persistent waves, some of which wait for a flag that another
+        // wave of the same kernel sets -- can then stall for good (cold starts of eight slots did, about one process in
+        // thirty; four slots never did in several hundred).
         int lo = 0, hi = 0;
         if (ctx->slot_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
             e = hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, hi);
@@ -1736,6 +1739,10 @@ int submit_frame(pt_ctx* ctx, const PtFrame* frame, uint32_t slot, void* host, v
     if (host) PT_HIP(ctx, hipMemcpyAsync(host, f16 ? static_cast<const void*>(out16) : static_cast<const void*>(out32), (f16 ? 8 : 16) * n_pix, hipMemcpyDeviceToHost, L.stream));
     L.submitted = true;   // (from here on the slot has to be waited for, whatever the record below returns)
     PT_HIP(ctx, hipEventRecord(L.ev_done, L.stream));
+    // Hand everything enqueued so far to the device now: the runtime may hold the tail of a stream's commands (the copy of
+    // the counters, the event markers) back until the stream is next touched, and with several slots in use a frame was
+    // seen to sit finished on the device while pt_render_wait for it did not return until another stream was queried.
+    (void)hipStreamQuery(L.stream);
     return PT_OK;
 }
 
@@ -1771,6 +1778,8 @@ int pt_render_wait(pt_ctx* ctx, uint32_t slot) {
         if (!L.submitted) return fail(ctx, PT_ERR_NOT_READY, "pt_render_wait: no frame has been submitted to slot " + std::to_string(slot));
         PT_HIP(ctx, hipSetDevice(ctx->device));
         L.submitted = false;   // (whatever happens below, the slot can be submitted to again)
+        for (Lane& other : ctx->lanes)      // (see submit_frame: nothing of any slot is to be left with the runtime)
+            if (other.ready && other.stream && &other != &L) (void)hipStreamQuery(other.stream);
         PT_HIP(ctx, hipStreamSynchronize(L.stream));
         ctx->cur_lane = 1u + slot;
         return finish_lane(ctx, L);
@@ -1909,6 +1918,34 @@ int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n
         return PT_OK;
     } catch (...) {
         return fail(ctx, PT_ERR_DEVICE, "pt_debug_wave_log: unexpected exception");
+    }
+}
+
+int pt_debug_slot_state(pt_ctx* ctx, uint32_t slot, uint32_t* out, uint32_t n_out) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    try {
+        if (!out || n_out < 16u || slot >= kMaxFrameSlots) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_debug_slot_state: bad argument");
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        Lane& L = ctx->lanes[1u + slot];
+        std::memset(out, 0, sizeof(uint32_t) * n_out);
+        out[0] = L.submitted ? 1u : 0u;
+        out[1] = L.ready ? (uint32_t)hipStreamQuery(L.stream) : 0xFFFFFFFFu;
+        out[2] = (uint32_t)L.frame_seq;
+        if (!L.ready) return PT_OK;
+        for (int k = 0; k < 2; ++k) {
+            FrameSlot& sl = L.slot[k];
+            uint32_t* o = out + 4 + 6 * k;
+            o[0] = sl.pending ? 1u : 0u;
+            o[1] = (uint32_t)hipEventQuery(sl.ev1);
+            DCounters c;
+            if (sl.counters.p && hipMemcpy(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess) {
+                o[2] = c.n_paths; o[3] = c.next_path; o[4] = c.waves_done; o[5] = (uint32_t)c.rays;
+            }
+        }
+        (void)hipGetLastError();
+        return PT_OK;
+    } catch (...) {
+        return fail(ctx, PT_ERR_DEVICE, "pt_debug_slot_state: unexpected exception");
     }
 }
 
