@@ -448,9 +448,10 @@ int pt_device_info(pt_ctx* ctx, char* buf, size_t buf_bytes);
 int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n_records);
 /* Where a slot's frames stand, without waiting for anything (for a watchdog that finds a wait not returning):
  * out[0] a frame is submitted, out[1] hipStreamQuery of the slot's stream (0: idle), out[2] frames enqueued so far; then for
- * each of the slot's two frame records six words: pending, hipEventQuery of its end event, and from its device counters
- * the entries of the path list, the queue head of k_paths, its waves that have left, the low word of its ray count.
- * `n_out` >= 16 words. No counterpart in the reference. */
+ * each of the slot's two frame records eight words: pending, hipEventQuery of its end event, and from its device counters
+ * the entries of the path list, the queue head of k_paths, its waves that have left, the low word of its ray count, the
+ * frames of the process that were running on the device when it was scheduled (bit 8: it was scheduled as sharing the
+ * device), its chunks handed out in parts. `n_out` >= 20 words. No counterpart in the reference. */
 int pt_debug_slot_state(pt_ctx* ctx, uint32_t slot, uint32_t* out, uint32_t n_out);
 
 /* Diagnostics: verifies on the device that every node box of the TLAS and of every

@@ -404,8 +404,8 @@ class Context:
         self._check(self._lib.pt_render_slot_wait_for(self._h, slot, C.c_void_p(stream) if stream else None))
 
     def slot_state(self, slot: int) -> np.ndarray:
-        """pt_debug_slot_state: 16 words on where the slot's frames stand; waits for nothing."""
-        out = np.zeros(16, dtype=np.uint32)
+        """pt_debug_slot_state: 20 words on where the slot's frames stand; waits for nothing."""
+        out = np.zeros(20, dtype=np.uint32)
         self._check(self._lib.pt_debug_slot_state(self._h, slot, _ptr(out), out.size))
         return out
 

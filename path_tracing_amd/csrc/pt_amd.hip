@@ -194,6 +194,8 @@ struct pt_ctx {
     uint32_t chunk_pixels = 64;   // see PathParams::chunk
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
+    uint32_t alone_streak = 0;    // consecutive submits on slots that found no frame of another slot waiting to be collected
+    bool sweeps_when_shared = false;   // PT_AMD_SWEEPS_SHARED=1: sample sweeps also for frames that run beside other frames (for measurements)
     std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
     bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
     int list_regs = 0;             // object-list variants of k_paths: 0 chosen per frame, 1 always the build for four waves per SIMD, 2 always the roomy one
@@ -534,6 +536,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (const char* e = std::getenv("PT_AMD_SLOT_PRIORITY")) ctx->slot_priority = std::atoi(e) != 0;
         if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
         if (std::getenv("PT_AMD_NO_QUEUE_AHEAD")) ctx->queue_ahead = false;
+        if (const char* e = std::getenv("PT_AMD_SWEEPS_SHARED")) ctx->sweeps_when_shared = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; else if (v == 8 || v == 16 || v == 32) ctx->chunk_pixels = (uint32_t)v; }
         std::snprintf(ctx->info, sizeof ctx->info, "pt_amd abi %d | %s %s | %d CUs | %d MHz | %.0f GiB", PT_ABI_VERSION, prop.name,
@@ -1504,7 +1507,19 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
         pp.split_chunks = ctx->split_chunks ? 1u : 0u;
         pp.carry_acquire = ctx->carry_acquire ? 1u : 0u;
         pp.sweep_end[0] = fp.samples;
-        if (pp.refill_min == 64u && pp.chunk == 64u && fp.samples >= 16u && ctx->max_sweeps > 1u) {
+        // Not for a frame that will run beside other frames (k_chunk_order has the reason). The kernel sees that for itself
+        // when another frame of the process is running as it is scheduled; the host sees the caller's pattern earlier: a
+        // frame on a slot gets sweeps only when this and the last two submits found every other slot collected, so a caller
+        // that keeps frames in flight never has a frame with sweeps among them, the first frames included.
+        bool beside_others = false;
+        if (!noalloc) {
+            bool others_pending = false;
+            for (const Lane& o : ctx->lanes)   // (slots only: a synchronous frame stays "pending" until its statistics are read)
+                if (&o != &L && &o != &ctx->lanes[0] && o.ready && (o.slot[0].pending || o.slot[1].pending)) others_pending = true;
+            if (&L != &ctx->lanes[0]) ctx->alone_streak = others_pending ? 0u : std::min(ctx->alone_streak + 1u, 1000u);
+            beside_others = !ctx->sweeps_when_shared && (others_pending || (&L != &ctx->lanes[0] && ctx->alone_streak < 3u));
+        }
+        if (pp.refill_min == 64u && pp.chunk == 64u && fp.samples >= 16u && ctx->max_sweeps > 1u && !beside_others) {
             uint32_t n = 0, done = 0, left = fp.samples;
             while (n + 1u < ctx->max_sweeps && left >= 8u) {
                 const uint32_t len = left / 2u;
@@ -1550,7 +1565,7 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
             ChunkOrderInfo* info = reinterpret_cast<ChunkOrderInfo*>(order + max_chunks);
             k_chunk_keys<<<div_up(max_chunks, 4), 256, 0, s>>>(w.cost, dc, fp.samples, L.d_chunk_bin.as<uint32_t>());
             PT_HIP(ctx, hipGetLastError());
-            k_chunk_order<<<1, 1024, 0, s>>>(L.d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction[0], ctx->split_fraction[1], ctx->group_margin_8ths[0], ctx->group_margin_8ths[1], ctx->n_cus, grid * 4u, ctx->split_load_8ths);
+            k_chunk_order<<<1, 1024, 0, s>>>(L.d_chunk_bin.as<uint32_t>(), dc, order, info, ctx->split_fraction[0], ctx->split_fraction[1], ctx->group_margin_8ths[0], ctx->group_margin_8ths[1], ctx->n_cus, grid * 4u, ctx->split_load_8ths, ctx->sweeps_when_shared ? 1u : (pp.n_sweeps == 1u ? 2u : 0u));
             if (hipGetLastError() == hipSuccess) {   // (not launched: the frame was not signed in and runs in list order)
                 chunk_order = order;
                 order_info = info;
@@ -1924,7 +1939,7 @@ int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n
 int pt_debug_slot_state(pt_ctx* ctx, uint32_t slot, uint32_t* out, uint32_t n_out) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     try {
-        if (!out || n_out < 16u || slot >= kMaxFrameSlots) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_debug_slot_state: bad argument");
+        if (!out || n_out < 20u || slot >= kMaxFrameSlots) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_debug_slot_state: bad argument");
         PT_HIP(ctx, hipSetDevice(ctx->device));
         Lane& L = ctx->lanes[1u + slot];
         std::memset(out, 0, sizeof(uint32_t) * n_out);
@@ -1934,12 +1949,13 @@ int pt_debug_slot_state(pt_ctx* ctx, uint32_t slot, uint32_t* out, uint32_t n_ou
         if (!L.ready) return PT_OK;
         for (int k = 0; k < 2; ++k) {
             FrameSlot& sl = L.slot[k];
-            uint32_t* o = out + 4 + 6 * k;
+            uint32_t* o = out + 4 + 8 * k;
             o[0] = sl.pending ? 1u : 0u;
             o[1] = (uint32_t)hipEventQuery(sl.ev1);
             DCounters c;
             if (sl.counters.p && hipMemcpy(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess) {
                 o[2] = c.n_paths; o[3] = c.next_path; o[4] = c.waves_done; o[5] = (uint32_t)c.rays;
+                o[6] = c.others_running; o[7] = c.n_split;
             }
         }
         (void)hipGetLastError();

@@ -357,6 +357,8 @@ __device__ uint32_t g_frames_running;
 __device__ unsigned long long g_last_shared_tick;
 struct ChunkOrderInfo {
     uint32_t n_chunks, n_heavy, n_split, n_groups;
+    uint32_t one_sweep;   // the frame shares the device: every chunk runs all its samples in one item (see k_chunk_order)
+    uint32_t pad[3];
 };
 __global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__ cost, const DCounters* __restrict__ counters,
                                                     uint32_t samples, uint32_t* __restrict__ chunk_bin) {
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void k_chunk_keys(const uint32_t* __restrict__
 __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict__ chunk_bin, DCounters* __restrict__ counters,
                                                       uint32_t* __restrict__ order, ChunkOrderInfo* __restrict__ info, uint32_t split_fraction_alone, uint32_t split_fraction_shared,
                                                       uint32_t margin_alone_8ths, uint32_t margin_shared_8ths, uint32_t min_groups,
-                                                      uint32_t launch_waves, uint32_t split_load_8ths) {
+                                                      uint32_t launch_waves, uint32_t split_load_8ths, uint32_t sweeps_rule) {
     __shared__ uint32_t cnt[PT_COST_BINS], start[PT_COST_BINS];
     const uint32_t total = counters->n_paths;
     const uint32_t n_chunks = (total + PT_CHUNK - 1u) / PT_CHUNK;
@@ -415,6 +417,13 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
         // by its longest chains; a frame with several times more work than the launch has waves is bound by throughput.
         const unsigned long long waves_needed = longest ? work / longest : 0ull;
         if (split_load_8ths && waves_needed * 8ull > (unsigned long long)launch_waves * split_load_8ths) split = 0;
+        // Sample sweeps shorten the tail of a frame that has the device to itself. Beside other frames there is no tail to
+        // shorten (their kernels fill the gaps; measured: the same time per frame with and without on every workload), and
+        // a wave that polls for a chunk's previous sweep would do so while the hardware shares its compute units between
+        // queues: frames that share the device run without sweeps, and so without any wait inside the kernel.
+        // sweeps_rule 0: that; 1: sweeps whatever runs beside the frame; 2: the host has already given the frame one sweep.
+        info->one_sweep = (sweeps_rule == 2u || (sweeps_rule == 0u && shared)) ? 1u : 0u;
+        if (info->one_sweep) { heavy = 0; split = 0; }
         info->n_chunks = n_chunks;
         info->n_heavy = heavy;
         info->n_split = split;
@@ -513,9 +522,10 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
     const uint32_t bounces = pp.bounces;
     // (read once: the line that holds n_paths also holds the queue head, which every wave keeps hitting with atomics)
     const uint32_t total = counters->n_paths;  // written by k_primary, which ran before on the same stream
-    const uint32_t n_heavy = (order_info && pp.n_sweeps > 1u) ? order_info->n_heavy : 0u;
+    const uint32_t n_sweeps = (order_info && order_info->one_sweep) ? 1u : pp.n_sweeps;
+    const uint32_t n_heavy = (order_info && n_sweeps > 1u) ? order_info->n_heavy : 0u;
     // (not for scenes staged in LDS: their rounds are bound by instruction issue and cost the same for 16 lanes as for 64)
-    const uint32_t n_split = (MODE != PT_MODE_LDS && order_info && pp.n_sweeps > 1u && pp.split_chunks) ? order_info->n_split : 0u;   // <= n_heavy
+    const uint32_t n_split = (MODE != PT_MODE_LDS && order_info && n_sweeps > 1u && pp.split_chunks) ? order_info->n_split : 0u;   // <= n_heavy
 
     LaneCounters cnt = {};
     uint32_t lane_rays = 0;
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                 // others with their first sweep; then sweep after sweep over the others.
                 const uint32_t n_chunks_total = (total + pp.chunk - 1u) / pp.chunk;
                 const uint32_t n_light = n_chunks_total - n_heavy;
-                const uint32_t n_items = n_chunks_total + (pp.n_sweeps - 1u) * n_light + (PT_SPLIT_PARTS - 1u) * n_split;
+                const uint32_t n_items = n_chunks_total + (n_sweeps - 1u) * n_light + (PT_SPLIT_PARTS - 1u) * n_split;
                 bool solo = false;   // the item just taken is a part of a split chunk: this wave takes nothing else with it
                 uint32_t chunk_next = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_NEXT]);
                 uint32_t chunk_end = __builtin_amdgcn_readfirstlane(sched[PT_SCHED_END]);
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                             sched[PT_SCHED_SWEEP] = j;
                         }
                         sw_begin = j ? pp.sweep_end[j - 1u] : 0u;
-                        const uint32_t sw_end = (cpos < n_heavy) ? pp.samples : pp.sweep_end[j];
+                        const uint32_t sw_end = (cpos < n_heavy || n_sweeps == 1u) ? pp.samples : pp.sweep_end[j];
                         sw_len = (sw_end - sw_begin) | (sw_end >= pp.samples ? 0x80000000u : 0u);
                         chunk_next = c * pp.chunk;
                         chunk_end = (total - chunk_next < pp.chunk) ? total : chunk_next + pp.chunk;
@@ -633,7 +643,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                             chunk_next = min(chunk_next + part * len, chunk_end);
                             chunk_end = min(chunk_next + len, chunk_end);
                         }
-                        if (pp.n_sweeps > 1u && cpos >= n_heavy) report = c;
+                        if (n_sweeps > 1u && cpos >= n_heavy) report = c;
                         if (STATS) {
                             if (n_chunks == 0) first_entry = chunk_next;
                             const unsigned long long now = __builtin_amdgcn_s_memtime();

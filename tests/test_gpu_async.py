@@ -203,6 +203,44 @@ def test_frames_in_flight_at_1080p_equal_one_at_a_time():
                 assert ctx.stats()["rays"] > 0
 
 
+def test_frames_that_share_the_device_run_without_sample_sweeps():
+    """A frame that has the device to itself runs its samples in sweeps and its most expensive chunks in parts; a frame
+    that is scheduled beside other frames runs every chunk in one item, so that no wave of it ever polls for another wave's
+    sweep while the hardware shares the compute units between queues. pt_debug_slot_state shows which way a frame was
+    scheduled; the images are the same either way."""
+    import time
+    scene = scenes.scene_glb_textured(1920, 1080, 16, 10)
+    times = [0.5, 1.5, 2.5]
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        want = [ctx.render(scene.frame(time=t)) for t in times]
+        bufs = [ctx.host_array(want[0].shape, np.float32) for _ in range(3)]
+        time.sleep(0.1)   # (the device remembers for 20 ms that frames shared it)
+        for _ in range(4):  # (a caller's first two frames on a slot run without sweeps: it might be about to keep several in flight)
+            ctx.submit(scene.frame(time=times[0]), 0, bufs[0])
+            ctx.wait(0)
+            assert np.array_equal(bufs[0].view(np.uint32), want[0].view(np.uint32))
+        st = ctx.slot_state(0)
+        records = [st[4 + 8 * k: 12 + 8 * k] for k in range(2)]
+        assert all(int(r[6]) == 0 for r in records), records            # nobody else was running
+        assert any(int(r[7]) > 0 for r in records), records             # chunks in parts: the frame was scheduled with sweeps
+        for rep in range(3):
+            for s, t in enumerate(times):
+                ctx.submit(scene.frame(time=t), s, bufs[s])
+            for s in range(3):
+                ctx.wait(s)
+                assert np.array_equal(bufs[s].view(np.uint32), want[s].view(np.uint32)), f"pass {rep}, slot {s}"
+        shared = 0
+        for s in range(3):
+            st = ctx.slot_state(s)
+            for k in range(2):
+                r = st[4 + 8 * k: 12 + 8 * k]
+                if int(r[6]) & 0x100:
+                    shared += 1
+                    assert int(r[7]) == 0, (s, k, r)
+        assert shared >= 3, shared
+
+
 def test_gpu_side_ordering_of_a_slot_against_a_consumer_stream():
     """pt_render_stream_wait / pt_render_slot_wait_for: a consumer on a stream of its own (here: a slow chain of device copies
     that ends by saving the slot's image) reads every frame behind the frame and before the slot's next frame overwrites it,
