@@ -896,11 +896,13 @@ hipError_t lane_init(pt_ctx* ctx, Lane& L, bool own_stream) {
     if (own_stream) {
         // PT_AMD_SLOT_PRIORITY=1: a priority of its own kind. The runtime keeps the hardware queues of each priority apart, so
         // the slots' streams then do not have to share the few queues a process has by default (four) with its other
-        // streams (the null stream, the context's upload stream, the host application's own), which would make two slots
-        // run their frames one after the other. Not the default: with more than four queues of that priority in use the
-        // scheduler swaps queues in and out, and k_paths -- persistent waves, some of which wait for a flag that another
-        // wave of the same kernel sets -- can then stall for good (cold starts of eight slots did, about one process in
-        // thirty; four slots never did in several hundred).
+        // streams (the null stream, the context's upload stream, the host application's own); where they do, the slots
+        // mostly run their frames one after the other (scene.glb with four slots: 21.5 ms per frame against 10.7).
+        // Not the default, because work of the two priorities side by side has stalled for good on this platform, waves
+        // standing still in the middle of their work: frames on more than four such streams while their waves still
+        // waited for each other inside k_paths (one process start in thirty), and copies on a caller's stream of the
+        // default priority that were ordered against two such slots (one run in ten of a test file). Raising
+        // GPU_MAX_HW_QUEUES in the environment gives the same overlap without priorities.
         int lo = 0, hi = 0;
         if (ctx->slot_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
             e = hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, hi);
