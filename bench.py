@@ -15,7 +15,8 @@ Frames are kept in flight (--frames-in-flight, default 3; 5 and 4 for the two wo
 pixels, cornell and scene_glb_textured) on ONE context: pt_render_submit_device on that many slots in turn, pt_render_wait
 on a slot before it is reused, so the start of a frame overlaps the tail of the previous one over one copy of the scene.
 (N > 1 ranks, whose frames are followed by a collective on a stream of torch's, use one context per frame in flight with
-pt_render_device on torch streams instead; `ms_per_step_contexts` times that arrangement on one GPU as well.)
+pt_render_device on torch streams instead; `ms_per_step_contexts` times that arrangement on one GPU as well, in a child
+process of its own.)
 
 Every step is a new frame the way the reference makes one (src/raytrace.wgsl:210, src/extract.rs:297-346): `time`
 advances, so every pixel draws new random numbers, and the object array is handed over again (unchanged, as the example
@@ -156,22 +157,28 @@ def main():
     # streams of its own on the device slows another one's overlapping frames down by a factor of up to two).
     child_extra = {}
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.only_timed and not args.default_hw_queues and not args.contexts:
-        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-        cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--repeats", str(max(1, min(args.repeats, 5))), "--only-timed", "--default-hw-queues"]
-        if args.frames_in_flight is not None:
-            cmd += ["--frames-in-flight", str(args.frames_in_flight)]
-        if args.spp:
-            cmd += ["--spp", str(args.spp)]
-        if args.fixed_time:
-            cmd += ["--fixed-time"]
-        print("[bench] child process with the default hardware-queue count ...", file=sys.stderr, flush=True)
-        try:
-            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=900)   # (its progress lines go to this process's stderr)
-            child_extra["ms_per_step_default_hw_queues"] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
-        except Exception as e:   # (reported, not fatal: the headline does not depend on it)
-            child_extra["ms_per_step_default_hw_queues"] = None
-            child_extra["default_hw_queues_error"] = repr(e)[:200]
+        def child(key, what, flags, env):
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
+                   "--repeats", str(max(1, min(args.repeats, 5))), "--only-timed"] + flags
+            if args.frames_in_flight is not None:
+                cmd += ["--frames-in-flight", str(args.frames_in_flight)]
+            if args.spp:
+                cmd += ["--spp", str(args.spp)]
+            if args.fixed_time:
+                cmd += ["--fixed-time"]
+            print(f"[bench] child process {what} ...", file=sys.stderr, flush=True)
+            try:
+                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=900)   # (its progress lines go to this process's stderr)
+                child_extra[key] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+            except Exception as e:   # (reported, not fatal: the headline does not depend on it)
+                child_extra[key] = None
+                child_extra[key + "_error"] = repr(e)[:200]
+        child("ms_per_step_default_hw_queues", "with the default hardware-queue count", ["--default-hw-queues"],
+              {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"})
+        # The arrangement of earlier records, one context (and one copy of the scene) per frame in flight, each driven with
+        # pt_render_device on a torch stream: in a process of its own as well, since its streams and the slots' streams of
+        # the headline arrangement together would outnumber the hardware queues.
+        child("ms_per_step_contexts", "with one context per frame in flight", ["--contexts"], dict(os.environ))
 
     import torch
     import torch.distributed as dist
@@ -480,17 +487,6 @@ def main():
         host16 = [ctx.host_array((H, W, 4), np.float16) for _ in range(F)]
         extra["ms_per_step_plugin_sync"] = round(float(np.median(timed(PluginSync(ctx, host16[0]), repeats=n_rep_other))) / args.steps * 1e3, 4)
         extra["ms_per_step_plugin_async"] = round(float(np.median(timed(Slots(ctx, F, host=host16, f16=True), repeats=n_rep_other))) / args.steps * 1e3, 4)
-        # the arrangement of earlier records: one context (and one copy of the scene) per frame in flight
-        streams.extend(torch.cuda.Stream(device) for _ in range(F))
-        cs_f = [abi.Context(device=local_rank) for _ in range(F)]
-        for c in cs_f:
-            c.upload_scene(scene)
-        for k in range(F):
-            cs_f[k].render_device(frame, bufs[k].data_ptr(), streams[k].cuda_stream)
-        torch.cuda.synchronize(device)
-        extra["ms_per_step_contexts"] = round(float(np.median(timed(Contexts(cs_f), repeats=n_rep_other))) / args.steps * 1e3, 4)
-        for c in cs_f:
-            c.close()
         extra.update(child_extra)
 
     # kernel durations (HIP events recorded by the library on the launch stream), one step at a time
