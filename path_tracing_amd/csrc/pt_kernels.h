@@ -467,6 +467,14 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
 #define PT_SLOT_ENTRY 16     // list entry; bit 31: this sweep ends the pixel
 #define PT_SLOT_PIX 17       // pixel number
 #define PT_LANE_SLOTS 18
+// PT_MODE_TLAS keeps no copy of the primary hit in LDS (a restarting lane reads its list entry again); the twelve words
+// hold what the lane does not need while it walks the tree instead: throughput, radiance, RNG state, bounce and ray
+// counts. Left in registers they were spilled to scratch memory every round, 20 words out and 31 back per lane, on the
+// same vector-memory path the walk's node fetches are bound by.
+#ifndef PT_TLAS_PARK
+#define PT_TLAS_PARK 1
+#endif
+#define PT_SLOT_PARK 0       // (PT_MODE_TLAS) ray_color xyz, color xyz, rng xyz, bounce, rays of the pixel, rays of the lane
 // PT_MODE_LDS only (small scenes leave the room): the part of the scatter evaluation of the primary hit that is the
 // same for every sample of the pixel (BrdfFrame: tangent frame, reflected ray, N.V, albedo), 13 more words per lane
 #define PT_SLOT_FRAME 18
@@ -496,6 +504,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
     PT_SCENE_VIEW_FROM_PARAMS()
     // [4 waves][stack_depth][64 lanes] stacks, [4 waves][lane_slots(MODE)][64 lanes], [4 waves][PT_SCHED_WORDS], staged scene
     constexpr uint32_t SLOTS = lane_slots(MODE);
+    constexpr bool TLAS_PARK = MODE == PT_MODE_TLAS && PT_TLAS_PARK != 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     const uint32_t lds_fixed = 4 * (stack_depth + SLOTS) * 64 + 4 * PT_SCHED_WORDS;
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + lds_fixed);
@@ -673,11 +682,13 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                         h.n = V3(rb.w, rc.x, rc.y);
                         rdir = V3(rc.z, rc.w, rd.x);
                         rng.x = __float_as_uint(rd.y); rng.y = __float_as_uint(rd.z); rng.z = __float_as_uint(rd.w);
-                        slot[(PT_SLOT_HIT + 0) * 64] = ra.y;
-                        slot[(PT_SLOT_HIT + 1) * 64] = h.p.x; slot[(PT_SLOT_HIT + 2) * 64] = h.p.y; slot[(PT_SLOT_HIT + 3) * 64] = h.p.z;
-                        slot[(PT_SLOT_HIT + 4) * 64] = h.n.x; slot[(PT_SLOT_HIT + 5) * 64] = h.n.y; slot[(PT_SLOT_HIT + 6) * 64] = h.n.z;
-                        slot[(PT_SLOT_HIT + 7) * 64] = h.u; slot[(PT_SLOT_HIT + 8) * 64] = h.v;
-                        slot[(PT_SLOT_DIR + 0) * 64] = rdir.x; slot[(PT_SLOT_DIR + 1) * 64] = rdir.y; slot[(PT_SLOT_DIR + 2) * 64] = rdir.z;
+                        if (!TLAS_PARK) {
+                            slot[(PT_SLOT_HIT + 0) * 64] = ra.y;
+                            slot[(PT_SLOT_HIT + 1) * 64] = h.p.x; slot[(PT_SLOT_HIT + 2) * 64] = h.p.y; slot[(PT_SLOT_HIT + 3) * 64] = h.p.z;
+                            slot[(PT_SLOT_HIT + 4) * 64] = h.n.x; slot[(PT_SLOT_HIT + 5) * 64] = h.n.y; slot[(PT_SLOT_HIT + 6) * 64] = h.n.z;
+                            slot[(PT_SLOT_HIT + 7) * 64] = h.u; slot[(PT_SLOT_HIT + 8) * 64] = h.v;
+                            slot[(PT_SLOT_DIR + 0) * 64] = rdir.x; slot[(PT_SLOT_DIR + 1) * 64] = rdir.y; slot[(PT_SLOT_DIR + 2) * 64] = rdir.z;
+                        }
                         nrays = 1;  // the primary ray, traced by k_primary
                         v3 sum = V3(0, 0, 0);
                         if (sw_begin != 0u) {  // resume
@@ -732,6 +743,25 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
         // A path that stops moves on to the pixel's next sample, whose first hit is the cached primary hit.
         // Returns false when the lane has run the last sample of its sweep.
+        // the primary hit of the lane's pixel (and, with_dir, the primary ray's direction)
+        auto primary_hit = [&](bool with_dir) {
+            if (TLAS_PARK) {
+                const PathRec* r = &recs[slot_u[PT_SLOT_ENTRY * 64] & 0x7FFFFFFFu];
+                const float4 ra = r->a, rb = r->b, rc = r->c;
+                h.mat = __float_as_uint(ra.y);
+                h.u = ra.z; h.v = ra.w;
+                h.p = V3(rb.x, rb.y, rb.z);
+                h.n = V3(rb.w, rc.x, rc.y);
+                if (with_dir) rdir = V3(rc.z, rc.w, r->d.x);
+            } else {
+                if (with_dir) rdir = V3(slot[(PT_SLOT_DIR + 0) * 64], slot[(PT_SLOT_DIR + 1) * 64], slot[(PT_SLOT_DIR + 2) * 64]);
+                h.mat = slot_u[(PT_SLOT_HIT + 0) * 64];
+                h.p = V3(slot[(PT_SLOT_HIT + 1) * 64], slot[(PT_SLOT_HIT + 2) * 64], slot[(PT_SLOT_HIT + 3) * 64]);
+                h.n = V3(slot[(PT_SLOT_HIT + 4) * 64], slot[(PT_SLOT_HIT + 5) * 64], slot[(PT_SLOT_HIT + 6) * 64]);
+                h.u = slot[(PT_SLOT_HIT + 7) * 64];
+                h.v = slot[(PT_SLOT_HIT + 8) * 64];
+            }
+        };
         auto next_sample = [&]() -> bool {
             const v3 sum = add3(V3(slot[(PT_SLOT_SUM + 0) * 64], slot[(PT_SLOT_SUM + 1) * 64], slot[(PT_SLOT_SUM + 2) * 64]), color);
             const uint32_t left = slot_u[PT_SLOT_LEFT * 64] - 1u;
@@ -757,14 +787,9 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
             slot_u[PT_SLOT_LEFT * 64] = left;
             bounce = 0;
             rpos = origin;
-            rdir = V3(slot[(PT_SLOT_DIR + 0) * 64], slot[(PT_SLOT_DIR + 1) * 64], slot[(PT_SLOT_DIR + 2) * 64]);
             ray_color = V3(1, 1, 1);
             color = V3(0, 0, 0);
-            h.mat = slot_u[(PT_SLOT_HIT + 0) * 64];
-            h.p = V3(slot[(PT_SLOT_HIT + 1) * 64], slot[(PT_SLOT_HIT + 2) * 64], slot[(PT_SLOT_HIT + 3) * 64]);
-            h.n = V3(slot[(PT_SLOT_HIT + 4) * 64], slot[(PT_SLOT_HIT + 5) * 64], slot[(PT_SLOT_HIT + 6) * 64]);
-            h.u = slot[(PT_SLOT_HIT + 7) * 64];
-            h.v = slot[(PT_SLOT_HIT + 8) * 64];
+            primary_hit(true);
             return true;
         };
         // what the surface emits, and whether the path stops on it (black albedo)
@@ -784,11 +809,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
         // making the whole wave loop here.
         bool pending = st == PT_ST_SHADE || st == PT_ST_RESTART;
         if (st == PT_ST_RESTART) {
-            h.mat = slot_u[(PT_SLOT_HIT + 0) * 64];
-            h.p = V3(slot[(PT_SLOT_HIT + 1) * 64], slot[(PT_SLOT_HIT + 2) * 64], slot[(PT_SLOT_HIT + 3) * 64]);
-            h.n = V3(slot[(PT_SLOT_HIT + 4) * 64], slot[(PT_SLOT_HIT + 5) * 64], slot[(PT_SLOT_HIT + 6) * 64]);
-            h.u = slot[(PT_SLOT_HIT + 7) * 64];
-            h.v = slot[(PT_SLOT_HIT + 8) * 64];
+            primary_hit(false);
             st = PT_ST_SHADE;
         }
         if (__any(pending)) {
@@ -887,9 +908,25 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
             // four lanes in five idle.
             if (__any(st == PT_ST_TRACE)) {
                 const bool tracing = st == PT_ST_TRACE;
+                if (TLAS_PARK) {
+                    float* pk = slot + PT_SLOT_PARK * 64;
+                    uint32_t* pku = slot_u + PT_SLOT_PARK * 64;
+                    pk[0 * 64] = ray_color.x; pk[1 * 64] = ray_color.y; pk[2 * 64] = ray_color.z;
+                    pk[3 * 64] = color.x; pk[4 * 64] = color.y; pk[5 * 64] = color.z;
+                    pku[6 * 64] = rng.x; pku[7 * 64] = rng.y; pku[8 * 64] = rng.z;
+                    pku[9 * 64] = bounce; pku[10 * 64] = nrays; pku[11 * 64] = lane_rays;
+                }
                 const WideRay wr = make_wide_ray(world_slab_ray(rpos, rdir));
                 wide_walk_resume<STATS, PT_BURST_TLAS>([&](uint32_t r, uint4& q0, uint4& q1, uint4& q2, uint4& q3) { tlas_fetch(sc, r, q0, q1, q2, q3); }, wr, wb.t, stk, ws, pp.walk_quota, cnt,
                                                        [&](uint32_t obj, int sp) { object_test<STATS, false>(sc, obj, rpos, rdir, wb, stk, sp, cnt); });
+                if (TLAS_PARK) {
+                    const float* pk = slot + PT_SLOT_PARK * 64;
+                    const uint32_t* pku = slot_u + PT_SLOT_PARK * 64;
+                    ray_color = V3(pk[0 * 64], pk[1 * 64], pk[2 * 64]);
+                    color = V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]);
+                    rng.x = pku[6 * 64]; rng.y = pku[7 * 64]; rng.z = pku[8 * 64];
+                    bounce = pku[9 * 64]; nrays = pku[10 * 64]; lane_rays = pku[11 * 64];
+                }
                 if (tracing && ws.node == PT_WALK_DONE) {
                     nrays++;
                     lane_rays++;
