@@ -472,9 +472,12 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
 // counts. Left in registers they were spilled to scratch memory every round, 20 words out and 31 back per lane, on the
 // same vector-memory path the walk's node fetches are bound by.
 #ifndef PT_TLAS_PARK
-#define PT_TLAS_PARK 1
+#define PT_TLAS_PARK 2
 #endif
-#define PT_SLOT_PARK 0       // (PT_MODE_TLAS) ray_color xyz, color xyz, rng xyz, bounce, rays of the pixel, rays of the lane
+// The same words hold the other half of the lane's state while it refills and shades: where its unfinished walk stands
+// (node, stack height) and the closest hit so far. The two never have to be in registers at the same time.
+#define PT_SLOT_PARK 0       // (PT_MODE_TLAS) during the walk: ray_color xyz, color xyz, rng xyz, bounce, rays of the pixel, rays of the lane
+                             //                otherwise: walk node, stack height, closest hit t, object, triangle, u, v
 // PT_MODE_LDS only (small scenes leave the room): the part of the scatter evaluation of the primary hit that is the
 // same for every sample of the pixel (BrdfFrame: tangent frame, reflected ray, N.V, albedo), 13 more words per lane
 #define PT_SLOT_FRAME 18
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
     // [4 waves][stack_depth][64 lanes] stacks, [4 waves][lane_slots(MODE)][64 lanes], [4 waves][PT_SCHED_WORDS], staged scene
     constexpr uint32_t SLOTS = lane_slots(MODE);
     constexpr bool TLAS_PARK = MODE == PT_MODE_TLAS && PT_TLAS_PARK != 0;
+    constexpr bool TLAS_PARK_WALK = MODE == PT_MODE_TLAS && PT_TLAS_PARK >= 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     const uint32_t lds_fixed = 4 * (stack_depth + SLOTS) * 64 + 4 * PT_SCHED_WORDS;
     if (MODE == PT_MODE_LDS) stage_scene_in_lds(sc, ls, s_mem + lds_fixed);
@@ -554,6 +558,13 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
     WalkState ws = {PT_WALK_DONE, 0};
     Best wb;
     wb.t = PT_T_MAX; wb.obj = PT_NONE; wb.tri = PT_NONE; wb.u = 0.0f; wb.v = 0.0f;
+    auto park_walk = [&]() {
+        float* pk = slot + PT_SLOT_PARK * 64;
+        uint32_t* pku = slot_u + PT_SLOT_PARK * 64;
+        pku[0 * 64] = ws.node; pku[1 * 64] = (uint32_t)ws.sp;
+        pk[2 * 64] = wb.t; pku[3 * 64] = wb.obj; pku[4 * 64] = wb.tri; pk[5 * 64] = wb.u; pk[6 * 64] = wb.v;
+    };
+    if (TLAS_PARK_WALK) park_walk();
     bool quad_wave = false;  // wave-uniform: the wave holds a portion of a split chunk, its pixels in lanes 0, 4, 8 ... (quads)
     bool exhausted = false;  // wave-uniform: the work queue has run out
     bool waiting = false;    // wave-uniform: holding an item whose chunk is not ready yet
@@ -887,6 +898,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                         ws.node = (sc.tlas_root == PT_NONE) ? PT_WALK_DONE : sc.tlas_root;
                         ws.sp = 0;
                         wb.t = PT_T_MAX; wb.obj = PT_NONE; wb.tri = PT_NONE; wb.u = 0.0f; wb.v = 0.0f;
+                        if (TLAS_PARK_WALK) park_walk();
                     }
                 }
             }
@@ -908,6 +920,12 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
             // four lanes in five idle.
             if (__any(st == PT_ST_TRACE)) {
                 const bool tracing = st == PT_ST_TRACE;
+                if (TLAS_PARK_WALK) {
+                    const float* pk = slot + PT_SLOT_PARK * 64;
+                    const uint32_t* pku = slot_u + PT_SLOT_PARK * 64;
+                    ws.node = pku[0 * 64]; ws.sp = (int)pku[1 * 64];
+                    wb.t = pk[2 * 64]; wb.obj = pku[3 * 64]; wb.tri = pku[4 * 64]; wb.u = pk[5 * 64]; wb.v = pk[6 * 64];
+                }
                 if (TLAS_PARK) {
                     float* pk = slot + PT_SLOT_PARK * 64;
                     uint32_t* pku = slot_u + PT_SLOT_PARK * 64;
@@ -934,6 +952,7 @@ __global__ __launch_bounds__(256, MODE == PT_MODE_TLAS ? PT_PATHS_MIN_WAVES_TLAS
                     h = finalize_hit<MODE != PT_MODE_LDS>(sc, rpos, rdir, wb);
                     st = PT_ST_SHADE;
                 }
+                if (TLAS_PARK_WALK) park_walk();
             }
         } else if (__any(st == PT_ST_TRACE)) {
             const bool tracing = st == PT_ST_TRACE;
