@@ -110,7 +110,6 @@ struct Lane {
         d_chunk_order, d_wave_log;
     uint32_t wave_log_records = 0;
     uint64_t last_n_paths = ~0ull;    // entries of the path list of the last frame read back
-    uint32_t last_waves_needed = 0;   // its work over its longest chunk, in waves (0: it was not ordered by hints)
     bool hint_valid = false;          // the aux ray-count plane holds a complete frame described by hint_key
     FrameKey hint_key;
     uint32_t aux_w = 0, aux_h = 0;
@@ -194,6 +193,7 @@ struct pt_ctx {
     uint32_t chunk_pixels = 64;   // see PathParams::chunk
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
+    uint32_t last_waves_needed = 0;   // the last frame that was ordered by cost hints: its work over its longest chunk, in waves (0: none yet)
     uint32_t alone_streak = 0;    // consecutive submits on slots that found no frame of another slot waiting to be collected
     bool sweeps_when_shared = false;   // PT_AMD_SWEEPS_SHARED=1: sample sweeps also for frames that run beside other frames (for measurements)
     std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
@@ -1183,7 +1183,7 @@ int finish_slot(pt_ctx* ctx, Lane& L, FrameSlot& sl) {
     st.lane_rounds = c.lane_rounds;
     st.object_passes = c.passes;
     L.last_n_paths = c.n_paths;
-    L.last_waves_needed = c.waves_needed;
+    if (c.waves_needed != 0u) ctx->last_waves_needed = c.waves_needed;
     st.wave_life_sum = c.wave_life_sum;
     st.wave_life_max = c.wave_life_max;
     st.waves = c.waves;
@@ -1488,12 +1488,15 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
             pp.tlas_top_n = std::min(os.tlas_n_wide, ctx->tlas_top_max == PT_NONE ? fit : ctx->tlas_top_max);
         }
         const size_t lds_paths = lds + (paths_mode == PT_MODE_LIST_LB ? lds_blas_bytes(lb.n_nodes, lb.n_tris) : 0u) + (size_t)pp.tlas_top_n * sizeof(WNode);
-        // Object-list scenes whose last finished frame had work for few waves (the sum of its chunk lengths over the longest:
-        // see ChunkOrderInfo) run the build with twice the registers and half the waves per SIMD.
+        // Object-list scenes whose last measured frame (of any slot, of any view) had work for few waves (the sum of its
+        // chunk lengths over the longest: see ChunkOrderInfo) run the build with more registers and fewer waves per SIMD,
+        // which keeps nothing in scratch memory; so do frames of a context that has no such measurement yet (its first
+        // frame, or cost hints switched off): scene.glb without hints 11.9 against 13.0 ms per frame, a scene of twelve
+        // overlapping meshes, which has many times the work, 23.7 against 22.0 for its first frame only.
         bool roomy = false;
         if (paths_mode == PT_MODE_LIST || paths_mode == PT_MODE_LIST_LB) {
             const uint64_t roomy_waves = (uint64_t)ctx->n_cus * 4u * PT_PATHS_MIN_WAVES_LIST_ROOMY;
-            roomy = ctx->list_regs == 2 || (ctx->list_regs == 0 && use_hint && L.last_waves_needed != 0u && (uint64_t)L.last_waves_needed <= 2u * roomy_waves);
+            roomy = ctx->list_regs == 2 || (ctx->list_regs == 0 && (ctx->last_waves_needed == 0u || (uint64_t)ctx->last_waves_needed <= 2u * roomy_waves));
         }
         PathsFn fn = (roomy ? ptable_roomy : ptable)[paths_mode][st ? 1 : 0];
         if (lds_paths > 64 * 1024) PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_paths));
