@@ -27,7 +27,8 @@ per frame (the schedule hints then come from a slightly different view), with th
 frame after a cut gets), and what a plugin that replaces RayTraceNode::run gets through the boundary, image delivered to
 page-locked host memory as binary16 each frame: synchronously (`ms_per_step_plugin_sync`: pt_render) and with frames in
 flight (`ms_per_step_plugin_async`: pt_render_submit / pt_render_wait); and the headline arrangement in a process that
-leaves HIP's hardware-queue count at its default (`ms_per_step_default_hw_queues`).
+leaves HIP's hardware-queue count at its default (`ms_per_step_default_hw_queues`), also in one that never loads torch
+(`ms_per_step_default_hw_queues_plain_hip`: --plain-hip).
 
 Prints ONE JSON line on rank 0.
 """
@@ -128,6 +129,79 @@ def cpu_baseline(scene, spp: int, min_seconds: float = 10.0):
                       f"({rays} rays in {dt:.2f} s; the restatement re-traces the primary ray for every sample as the reference does)"}
 
 
+def plain_hip_timed(args):
+    """--plain-hip: the --only-timed measurement of the headline arrangement (F slots of one context, a new frame every
+    step, images left in device memory) in a process that never loads torch, i.e. on the system's HIP runtime with no
+    streams but the library's own -- what a host application written against the C ABI gets. Device images come from
+    hipMalloc; the timed region is bracketed by hipDeviceSynchronize."""
+    import ctypes as C
+    desc, make = WORKLOADS[args.workload]
+    scene = make()
+    if args.spp:
+        scene.samples = args.spp
+    F = max(1, args.frames_in_flight if args.frames_in_flight is not None else FRAMES_IN_FLIGHT.get(args.workload, 3))
+    if F > abi.PT_MAX_FRAME_SLOTS:
+        raise SystemExit(f"--frames-in-flight: at most {abi.PT_MAX_FRAME_SLOTS}")
+    abi.load_library()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    frames = [scene.frame(time=virtual_frame_time(0)) for _ in range(F)]
+    nbytes = frames[0].width * frames[0].height * 16
+    bufs = [C.c_void_p() for _ in range(F)]
+    for b in bufs:
+        if hip.hipMalloc(C.byref(b), nbytes) != 0:
+            raise SystemExit("hipMalloc failed")
+    times = []
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        busy = [False] * F
+        step_no = [0]
+
+        def step():
+            i = step_no[0]
+            s = i % F
+            step_no[0] += 1
+            if busy[s]:
+                ctx.wait(s)
+            frames[s].time = 0.0 if args.fixed_time else virtual_frame_time(i)
+            ctx.upload_objects(scene.objects)
+            ctx.submit_device(frames[s], s, bufs[s].value)
+            busy[s] = True
+
+        def drain():
+            for s in range(F):
+                if busy[s]:
+                    ctx.wait(s)
+                    busy[s] = False
+
+        for _ in range(args.warmup):
+            step()
+        drain()
+        reps = args.repeats
+        r = 0
+        while r < reps:
+            hip.hipDeviceSynchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            drain()
+            hip.hipDeviceSynchronize()
+            times.append(time.perf_counter() - t0)
+            r += 1
+            print(f"[bench] plain HIP: repeat {r} of {reps}: {times[-1] / args.steps * 1e3:.4f} ms per step", file=sys.stderr, flush=True)
+            if r == 1:
+                reps = max(1, min(reps, int(8.0 / max(times[0], 1e-9))))
+        rays = ctx.stats()["rays"]
+    for b in bufs:
+        hip.hipFree(b)
+    print(json.dumps({"only_timed": True, "workload": args.workload, "frames_in_flight": F, "steps": args.steps, "repeats": len(times),
+                      "arrangement": "slots of one context", "host": "plain HIP (torch never loaded)",
+                      "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"),
+                      "ms_per_step": round(float(np.median(times)) / args.steps * 1e3, 4), "ms_per_step_min": round(float(np.min(times)) / args.steps * 1e3, 4),
+                      "rays_per_step": int(rays)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,7 +224,13 @@ def main():
     ap.add_argument("--default-hw-queues", action="store_true", help="do not raise GPU_MAX_HW_QUEUES (HIP's default is 4 hardware queues per process)")
     ap.add_argument("--contexts", action="store_true", help="one GPU: keep the frames in flight on one context each (pt_render_device on torch "
                     "streams) instead of on the slots of one context")
+    ap.add_argument("--plain-hip", action="store_true", help="with --only-timed on one GPU: the same timing in a process that never loads torch "
+                    "(device images from hipMalloc); what a host application on the system's HIP runtime gets")
     args = ap.parse_args()
+    if args.plain_hip:
+        if not args.only_timed or args.gpus != 1 or args.contexts or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--plain-hip goes with --only-timed on one GPU (slots of one context)")
+        return plain_hip_timed(args)
 
     # The headline arrangement in a process that leaves HIP's hardware-queue count alone, measured first: a child process
     # of its own, run to its end before this process creates its GPU state (a process that merely holds contexts and
@@ -174,6 +254,10 @@ def main():
                 child_extra[key] = None
                 child_extra[key + "_error"] = repr(e)[:200]
         child("ms_per_step_default_hw_queues", "with the default hardware-queue count", ["--default-hw-queues"],
+              {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"})
+        # ... and the same without torch in the process: torch brings its own HIP runtime and streams, which take hardware
+        # queues too; a host application written against the C ABI has the four default queues to itself
+        child("ms_per_step_default_hw_queues_plain_hip", "with the default hardware-queue count, torch never loaded", ["--default-hw-queues", "--plain-hip"],
               {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"})
         # The arrangement of earlier records, one context (and one copy of the scene) per frame in flight, each driven with
         # pt_render_device on a torch stream: in a process of its own as well, since its streams and the slots' streams of
