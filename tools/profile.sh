@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH3="python3 $R/bench.py --steps 20 --warmup 3 --repeats 1 --only-timed --no-cpu-baseline $*"           # frames in flight: the bench's default
-BENCH="python3 $R/bench.py --steps 5 --warmup 1 --repeats 1 --only-timed --no-cpu-baseline --frames-in-flight 1 $*"   # one frame at a time: kernels alone on the chip
+BENCH="python3 $R/bench.py --steps 5 --warmup 3 --repeats 1 --only-timed --no-cpu-baseline --frames-in-flight 1 $*"   # one frame at a time: kernels alone on the chip
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_fif" -- $BENCH3 > "$OUT/trace_fif.log" 2>&1 || { echo "trace (frames in flight) pass failed"; tail -5 "$OUT/trace_fif.log"; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc_sq" -- $BENCH > "$OUT/pmc_sq.log" 2>&1 || { echo "sq pass failed"; tail -5 "$OUT/pmc_sq.log"; exit 1; }

@@ -29,15 +29,21 @@ def is_stats_variant(name):
     return re.search(r"<\d+, true[,>]", name.split("(")[0]) is not None
 
 
-def read_counters(d, kernel):
+def read_counters(d, kernel, last):
+    """Average per launch over the last `last` dispatches of the kernel (the bench's timed region: the frames before it
+    are the first ones of a slot, which the library schedules without sample sweeps until it has seen the caller's pattern)."""
     files = glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True)
     per = defaultdict(lambda: defaultdict(float))   # counter -> dispatch -> value
     for f in files:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if kernel in row["Kernel_Name"] and not is_stats_variant(row["Kernel_Name"]):
-                    per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-    return {c: (sum(v.values()) / len(v), len(v)) for c, v in per.items()}
+                    per[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
+    out = {}
+    for c, v in per.items():
+        ids = sorted(v)[-last:]
+        out[c] = (sum(v[i] for i in ids) / len(ids), len(ids))
+    return out
 
 
 def main():
@@ -46,6 +52,7 @@ def main():
     ap.add_argument("--kernel", default="k_paths")
     ap.add_argument("--workload", default="boxes")
     ap.add_argument("--fif-steps", type=int, default=20, help="frames of the timed region in the frames-in-flight trace")
+    ap.add_argument("--alone-steps", type=int, default=5, help="frames of the timed region in the one-frame-at-a-time passes")
     ap.add_argument("--fetch-factor", type=float, default=None, help="bytes per byte FETCH_SIZE reports (default: 1 for instanced_boxes, else 2)")
     args = ap.parse_args()
     src = ROOT / "gpurun_out" / f"prof_{args.tag}"
@@ -62,17 +69,22 @@ def main():
                                 "pct": float(r["Percentage"])} for r in rows[:8]]
         for r in rows:
             if args.kernel in r["Name"] and not is_stats_variant(r["Name"]):
-                out["avg_kernel_ms"] = float(r["AverageNs"]) / 1e6
+                out["avg_kernel_ms_all_calls"] = float(r["AverageNs"]) / 1e6
                 out["calls"] = int(r["Calls"])
                 break
     trace = glob.glob(str(src / "trace" / "**" / "*kernel_trace.csv"), recursive=True)
     if trace:
         with open(trace[0]) as fh:
-            for r in csv.DictReader(fh):
-                if args.kernel in r["Kernel_Name"] and not is_stats_variant(r["Kernel_Name"]):
-                    out["launch"] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
-                                                       "Workgroup_Size_X", "Grid_Size_X")}
-                    break
+            mine = [r for r in csv.DictReader(fh) if args.kernel in r["Kernel_Name"] and not is_stats_variant(r["Kernel_Name"])]
+        if mine:
+            r = mine[0]
+            out["launch"] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                                               "Workgroup_Size_X", "Grid_Size_X")}
+            # the kernel's duration: mean over the timed region, i.e. the last `alone_steps` launches of the trace
+            mine.sort(key=lambda r: int(r["Start_Timestamp"]))
+            last = mine[-args.alone_steps:]
+            out["avg_kernel_ms"] = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last) / len(last) / 1e6
+            out["avg_kernel_ms_launches"] = len(last)
     # Frames in flight as the bench runs them: the last `fif_steps` frames of that trace are its timed region. Per-step wall
     # time from the device timestamps, and how much the frames overlap (kernel time summed over wall time; share of the
     # wall time in which kernels of two or more frames run at once). The rows used are copied to profiles/ as well.
@@ -123,7 +135,7 @@ def main():
                     out["frames_in_flight_trace_bench_line"] = json.loads(line)
     counters = {}
     for sub in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
-        for c, (avg, n) in read_counters(src / sub, args.kernel).items():
+        for c, (avg, n) in read_counters(src / sub, args.kernel, args.alone_steps).items():
             counters[c] = avg
     out["counters_per_launch"] = counters
     if "SQ_WAVE_CYCLES" in counters and counters.get("SQ_WAVE_CYCLES"):
