@@ -147,6 +147,7 @@ struct pt_ctx {
     PtConfig cfg{};
     int device = 0;
     hipStream_t stream = nullptr;   // uploads, builds, queries, and the frames of the synchronous entry points
+    hipStream_t debug_stream = nullptr;   // pt_debug_slot_state: made at its first call, so that its copies wait for no other stream
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
     Lane lanes[kMaxLanes];
     uint32_t cur_lane = 0;        // the lane pt_get_stats / pt_read_aux / pt_debug_wave_log describe: that of the last frame completed
@@ -612,6 +613,7 @@ int pt_destroy(pt_ctx* ctx) {
     if (ctx->evb1) (void)hipEventDestroy(ctx->evb1);
     if (ctx->ev_noalloc) (void)hipEventDestroy(ctx->ev_noalloc);
     if (ctx->ev_acc) (void)hipEventDestroy(ctx->ev_acc);
+    if (ctx->debug_stream) (void)hipStreamDestroy(ctx->debug_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PT_OK;
@@ -1948,6 +1950,7 @@ int pt_debug_slot_state(pt_ctx* ctx, uint32_t slot, uint32_t* out, uint32_t n_ou
         PT_HIP(ctx, hipSetDevice(ctx->device));
         Lane& L = ctx->lanes[1u + slot];
         std::memset(out, 0, sizeof(uint32_t) * n_out);
+        if (!ctx->debug_stream) PT_HIP(ctx, hipStreamCreateWithFlags(&ctx->debug_stream, hipStreamNonBlocking));
         out[0] = L.submitted ? 1u : 0u;
         out[1] = L.ready ? (uint32_t)hipStreamQuery(L.stream) : 0xFFFFFFFFu;
         out[2] = (uint32_t)L.frame_seq;
@@ -1958,7 +1961,8 @@ int pt_debug_slot_state(pt_ctx* ctx, uint32_t slot, uint32_t* out, uint32_t n_ou
             o[0] = sl.pending ? 1u : 0u;
             o[1] = (uint32_t)hipEventQuery(sl.ev1);
             DCounters c;
-            if (sl.counters.p && hipMemcpy(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (sl.counters.p && hipMemcpyAsync(&c, sl.counters.p, sizeof c, hipMemcpyDeviceToHost, ctx->debug_stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->debug_stream) == hipSuccess) {
                 o[2] = c.n_paths; o[3] = c.next_path; o[4] = c.waves_done; o[5] = (uint32_t)c.rays;
                 o[6] = c.others_running; o[7] = c.n_split;
             }
