@@ -384,7 +384,30 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
     const uint32_t n_chunks = (total + PT_CHUNK - 1u) / PT_CHUNK;
     if (threadIdx.x < PT_COST_BINS) cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024u) atomicAdd(&cnt[chunk_bin[c]], 1u);
+    // One workgroup walks the bins of all chunks twice. Eight loads are in flight per thread (the passes are a chain of
+    // memory round trips otherwise), and most chunks of a frame share a few bins: one atomic per wave and bin, not per chunk.
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr uint32_t BATCH = 8u;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += BATCH * 1024u) {
+        uint32_t bins[BATCH];
+#pragma unroll
+        for (uint32_t k = 0; k < BATCH; ++k) {
+            const uint32_t c = c0 + k * 1024u + threadIdx.x;
+            bins[k] = c < n_chunks ? chunk_bin[c] : PT_NONE;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < BATCH; ++k) {
+            const uint32_t b = bins[k];
+            unsigned long long todo = __ballot(b != PT_NONE);
+            while (todo != 0ull) {
+                const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+                const uint32_t lb = __shfl(b, (int)leader, 64);
+                const unsigned long long same = __ballot(b == lb);
+                if (lane == leader) atomicAdd(&cnt[lb], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         // other frames on the device? (see g_frames_running)
@@ -436,7 +459,29 @@ __global__ __launch_bounds__(1024) void k_chunk_order(const uint32_t* __restrict
         counters->others_running = others | (shared ? 0x100u : 0u);
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024u) order[atomicAdd(&start[chunk_bin[c]], 1u)] = c;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += BATCH * 1024u) {
+        uint32_t bins[BATCH];
+#pragma unroll
+        for (uint32_t k = 0; k < BATCH; ++k) {
+            const uint32_t c = c0 + k * 1024u + threadIdx.x;
+            bins[k] = c < n_chunks ? chunk_bin[c] : PT_NONE;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < BATCH; ++k) {
+            const uint32_t b = bins[k];
+            unsigned long long todo = __ballot(b != PT_NONE);
+            while (todo != 0ull) {
+                const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+                const uint32_t lb = __shfl(b, (int)leader, 64);
+                const unsigned long long same = __ballot(b == lb);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&start[lb], (uint32_t)__popcll(same));
+                base = __shfl(base, (int)leader, 64);
+                if (b == lb) order[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = c0 + k * 1024u + threadIdx.x;
+                todo &= ~same;
+            }
+        }
+    }
 }
 
 // ---- path pass -----------------------------------------------------------------------------------------------
