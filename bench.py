@@ -11,7 +11,7 @@ with one RCCL all-reduce per step: N x 64 spp per step, per-GPU work fixed (weak
 `--multi-gpu tiles` instead splits the 8x8 tiles of ONE frame over the ranks (all-reduce = gather, image
 bit-identical to the one-GPU image, strong scaling).
 
-Frames are kept in flight (--frames-in-flight, default 3; 5 and 4 for the two workloads whose frames are chains of few
+Frames are kept in flight (--frames-in-flight, default 3; 8 for the two workloads whose frames are chains of few
 pixels, cornell and scene_glb_textured) on ONE context: pt_render_submit_device on that many slots in turn, pt_render_wait
 on a slot before it is reused, so the start of a frame overlaps the tail of the previous one over one copy of the scene.
 (N > 1 ranks, whose frames are followed by a collective on a stream of torch's, use one context per frame in flight with
@@ -49,8 +49,12 @@ import numpy as np
 # RCCL's; with 8 a kernel trace still showed the fourth of four frame streams on the third one's queue, with 16 up to
 # six streams ran side by side (read by the runtime when it initialises, i.e. before torch is imported).
 # --default-hw-queues leaves the variable alone (the child process behind `ms_per_step_default_hw_queues`).
-if "--default-hw-queues" not in sys.argv and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
-    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+# This process asks for 24: at times it holds two contexts with up to eight slots each (the headline's and the one
+# without cost hints), and the arrangement with one context per frame in flight (--contexts, N > 1 ranks) has an upload
+# stream and a torch stream per frame. A host application with one context needs its slots + 2.
+_HW_QUEUES = 24
+if "--default-hw-queues" not in sys.argv and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < _HW_QUEUES:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(_HW_QUEUES)
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -86,9 +90,10 @@ WORKLOADS = {
 }
 
 
-# Frames kept in flight by default (ms per frame at 3 / 4 / 5 / 6 with 16 hardware queues: boxes 1.52 / 1.60 / 1.63 / 1.59,
-# cornell 0.466 / 0.433 / 0.413 / 0.412, scene_glb_textured 11.0 / 10.7 / 10.9 / 11.1)
-FRAMES_IN_FLIGHT = {"cornell": 5, "scene_glb_textured": 4}
+# Frames kept in flight by default (ms per frame at 3 / 4 / 5 / 6 / 8 with 16 hardware queues: boxes 1.52 / 1.51 / 1.55 / 1.55 / 1.54,
+# cornell 0.47 / 0.43 / 0.40 / 0.39 / 0.37, scene_glb_textured 11.0 / 10.5 / 9.7 / 9.4 / 8.8 -- from five on the library serves
+# object-list scenes for throughput: no BLAS in LDS, no chunks in parts)
+FRAMES_IN_FLIGHT = {"cornell": 8, "scene_glb_textured": 8}
 
 
 def virtual_frame_time(rank: int) -> float:
@@ -307,7 +312,14 @@ def main():
     if F > abi.PT_MAX_FRAME_SLOTS:
         raise SystemExit(f"--frames-in-flight: at most {abi.PT_MAX_FRAME_SLOTS}")
     use_slots = world == 1 and not args.contexts
+    # (one context per frame in flight: a context sees only its own frame, so it is told that the pipeline is deep --
+    # object-list scenes are then served for throughput, as the slots of one context find out for themselves)
+    deep = not use_slots and F >= 5 and "PT_AMD_DEEP_PIPELINE" not in os.environ
+    if deep:
+        os.environ["PT_AMD_DEEP_PIPELINE"] = "0"
     ctxs = [abi.Context(device=local_rank) for _ in range(1 if use_slots else F)]
+    if deep:
+        del os.environ["PT_AMD_DEEP_PIPELINE"]
     for c in ctxs:
         c.upload_scene(scene)
     ctx = ctxs[0]

@@ -195,6 +195,7 @@ struct pt_ctx {
     uint32_t refill_min = 0;      // see PathParams::refill_min; 0 = choose per scene
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
     uint32_t last_waves_needed = 0;   // the last frame that was ordered by cost hints: its work over its longest chunk, in waves (0: none yet)
+    uint32_t deep_pipeline_slots = 4;   // frames of other slots in flight from which object-list scenes are served for throughput (PT_AMD_DEEP_PIPELINE; 0: always, 99: never)
     uint32_t alone_streak = 0;    // consecutive submits on slots that found no frame of another slot waiting to be collected
     bool sweeps_when_shared = false;   // PT_AMD_SWEEPS_SHARED=1: sample sweeps also for frames that run beside other frames (for measurements)
     std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
@@ -537,6 +538,7 @@ int pt_create(const PtConfig* cfg, pt_ctx** out_ctx) {
         if (const char* e = std::getenv("PT_AMD_SLOT_PRIORITY")) ctx->slot_priority = std::atoi(e) != 0;
         if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
         if (std::getenv("PT_AMD_NO_QUEUE_AHEAD")) ctx->queue_ahead = false;
+        if (const char* e = std::getenv("PT_AMD_DEEP_PIPELINE")) { int v = std::atoi(e); if (v >= 0 && v <= 99) ctx->deep_pipeline_slots = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_SWEEPS_SHARED")) ctx->sweeps_when_shared = std::atoi(e) != 0;
         if (const char* e = std::getenv("PT_AMD_SWEEPS")) { int v = std::atoi(e); if (v >= 1 && v <= PT_MAX_SWEEPS) ctx->max_sweeps = (uint32_t)v; }
         if (const char* e = std::getenv("PT_AMD_CHUNK")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) ctx->chunk_pixels = (uint32_t)(v / 64) * 64; else if (v == 8 || v == 16 || v == 32) ctx->chunk_pixels = (uint32_t)v; }
@@ -1454,6 +1456,16 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
                                              {k_paths<PT_MODE_LIST_LB, false>, k_paths<PT_MODE_LIST_LB, true>}};
         static const PathsFn ptable_roomy[4][2] = {{k_paths<PT_MODE_LIST, false, true>, k_paths<PT_MODE_LIST, true, true>}, {nullptr, nullptr}, {nullptr, nullptr},
                                                    {k_paths<PT_MODE_LIST_LB, false, true>, k_paths<PT_MODE_LIST_LB, true, true>}};
+        // Frames of other slots that wait to be collected as this one is enqueued: how deep the caller's pipeline is.
+        uint32_t n_others_pending = 0;
+        if (!noalloc)
+            for (const Lane& o : ctx->lanes)   // (slots only: a synchronous frame stays "pending" until its statistics are read)
+                if (&o != &L && &o != &ctx->lanes[0] && o.ready && (o.slot[0].pending || o.slot[1].pending)) n_others_pending++;
+        // With five or more frames in flight an object-list scene is served for throughput: no BLAS in LDS and no chunks
+        // in parts, both of which shorten a frame's longest chains at the price of workgroups per compute unit and idle
+        // lanes -- the other frames' waves cover those chains instead (scene.glb with eight slots: 8.8 against 9.8 ms per
+        // frame; with four the two arrangements are level, with three this one loses).
+        const bool deep_pipeline = n_others_pending >= ctx->deep_pipeline_slots;
         // Object-list scenes with a big mesh: its whole BLAS (and its triangles if they fit as well) goes into LDS,
         // at the price of fewer workgroups per compute unit. Rays in such a mesh are chains of dependent node
         // visits, each a round trip to the L2 otherwise.
@@ -1462,7 +1474,7 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
         int paths_mode = mode;
         // Only when the last finished frame of this view listed so few pixels that one workgroup per compute unit
         // takes them all anyway (a frame full of such pixels is better served by more workgroups).
-        if (mode == PT_MODE_LIST && ctx->lds_blas && use_hint && L.last_n_paths <= (uint64_t)ctx->n_cus * 256u * 4u) {
+        if (mode == PT_MODE_LIST && ctx->lds_blas && !deep_pipeline && use_hint && L.last_n_paths <= (uint64_t)ctx->n_cus * 256u * 4u) {
             const size_t budget = (size_t)ctx->lds_per_cu > lds + 1024 ? (size_t)ctx->lds_per_cu - 1024 - lds : 0;
             uint32_t best = PT_NONE;
             for (uint32_t m = 0; m < ctx->n_meshes; ++m) {
@@ -1511,7 +1523,7 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
         // short. Only with whole-chunk refill (a wave then owns one chunk at a time and can report it complete).
         pp.n_sweeps = 1;
         pp.walk_quota = ctx->walk_quota;
-        pp.split_chunks = ctx->split_chunks ? 1u : 0u;
+        pp.split_chunks = (ctx->split_chunks && !(deep_pipeline && mode == PT_MODE_LIST)) ? 1u : 0u;
         pp.carry_acquire = ctx->carry_acquire ? 1u : 0u;
         pp.sweep_end[0] = fp.samples;
         // Not for a frame that will run beside other frames (k_chunk_order has the reason). The kernel sees that for itself
@@ -1520,9 +1532,7 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
         // that keeps frames in flight never has a frame with sweeps among them, the first frames included.
         bool beside_others = false;
         if (!noalloc) {
-            bool others_pending = false;
-            for (const Lane& o : ctx->lanes)   // (slots only: a synchronous frame stays "pending" until its statistics are read)
-                if (&o != &L && &o != &ctx->lanes[0] && o.ready && (o.slot[0].pending || o.slot[1].pending)) others_pending = true;
+            const bool others_pending = n_others_pending != 0u;
             if (&L != &ctx->lanes[0]) ctx->alone_streak = others_pending ? 0u : std::min(ctx->alone_streak + 1u, 1000u);
             beside_others = !ctx->sweeps_when_shared && (others_pending || (&L != &ctx->lanes[0] && ctx->alone_streak < 3u));
         }
