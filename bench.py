@@ -12,7 +12,7 @@ with one RCCL all-reduce per step: N x 64 spp per step, per-GPU work fixed (weak
 bit-identical to the one-GPU image, strong scaling).
 
 Frames are kept in flight (--frames-in-flight, default 3; 8 for the two workloads whose frames are chains of few
-pixels, cornell and scene_glb_textured) on ONE context: pt_render_submit_device on that many slots in turn, pt_render_wait
+pixels, cornell and scene_glb_textured, 4 for instanced_boxes) on ONE context: pt_render_submit_device on that many slots in turn, pt_render_wait
 on a slot before it is reused, so the start of a frame overlaps the tail of the previous one over one copy of the scene.
 (N > 1 ranks, whose frames are followed by a collective on a stream of torch's, use one context per frame in flight with
 pt_render_device on torch streams instead; `ms_per_step_contexts` times that arrangement on one GPU as well, in a child
@@ -93,7 +93,7 @@ WORKLOADS = {
 # Frames kept in flight by default (ms per frame at 3 / 4 / 5 / 6 / 8 with 16 hardware queues: boxes 1.52 / 1.51 / 1.55 / 1.55 / 1.54,
 # cornell 0.47 / 0.43 / 0.40 / 0.39 / 0.37, scene_glb_textured 11.0 / 10.5 / 9.7 / 9.4 / 8.8 -- from five on the library serves
 # object-list scenes for throughput: no BLAS in LDS, no chunks in parts)
-FRAMES_IN_FLIGHT = {"cornell": 8, "scene_glb_textured": 8}
+FRAMES_IN_FLIGHT = {"cornell": 8, "scene_glb_textured": 8, "instanced_boxes": 4}   # (instanced_boxes at 3 / 4 / 5: 354 / 342 / 339 ms)
 
 
 def virtual_frame_time(rank: int) -> float:
