@@ -447,7 +447,10 @@ int pt_device_info(pt_ctx* ctx, char* buf, size_t buf_bytes);
  * Copies at most out_bytes; *n_records = records available. Profiling aid, no counterpart in the reference. */
 int pt_debug_wave_log(pt_ctx* ctx, void* out_host, size_t out_bytes, uint32_t* n_records);
 /* Where a slot's frames stand, without waiting for anything (for a watchdog that finds a wait not returning):
- * out[0] a frame is submitted, out[1] hipStreamQuery of the slot's stream (0: idle), out[2] frames enqueued so far; then for
+ * out[0] a frame is submitted, out[1] hipStreamQuery of the slot's stream (0: idle), out[2] frames enqueued so far, out[3] how
+ * the path kernel of the slot's last frame was set up (bit 31 set; bits 0-3 closest-hit organisation: 0 object list, 1 TLAS,
+ * 2 scene in LDS, 3 object list with a BLAS in LDS; bit 4 the build with more registers; bit 5 served for throughput because
+ * of the frames in flight; bits 8-11 frames of other slots in flight when it was enqueued); then for
  * each of the slot's two frame records eight words: pending, hipEventQuery of its end event, and from its device counters
  * the entries of the path list, the queue head of k_paths, its waves that have left, the low word of its ray count, the
  * frames of the process that were running on the device when it was scheduled (bit 8: it was scheduled as sharing the

@@ -105,6 +105,7 @@ struct Lane {
     hipStream_t stream = nullptr;     // lane 0: the context's stream; else a stream of its own
     FrameSlot slot[2];                // host-visible records of the two most recent frames
     uint64_t frame_seq = 0;           // frames enqueued so far; frame n uses slot[n & 1]
+    uint32_t last_schedule = 0;       // how the last frame's k_paths was set up (pt_debug_slot_state, out[3])
     hipStream_t last_frame_stream = nullptr;
     DevBuf d_stack_overflow, d_out, d_out16, d_aux_obj, d_aux_flat, d_aux_t, d_aux_rays, d_paths, d_sweeps_done, d_carry, d_cost, d_chunk_bin,
         d_chunk_order, d_wave_log;
@@ -1513,6 +1514,7 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
             roomy = ctx->list_regs == 2 || (ctx->list_regs == 0 && (ctx->last_waves_needed == 0u || (uint64_t)ctx->last_waves_needed <= 2u * roomy_waves));
         }
         PathsFn fn = (roomy ? ptable_roomy : ptable)[paths_mode][st ? 1 : 0];
+        if (!noalloc) L.last_schedule = 0x80000000u | (uint32_t)paths_mode | (roomy ? 0x10u : 0u) | (deep_pipeline ? 0x20u : 0u) | (std::min(n_others_pending, 15u) << 8);
         if (lds_paths > 64 * 1024) PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_paths));
         int per_cu = 0;
         PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds_paths));
@@ -1964,6 +1966,7 @@ int pt_debug_slot_state(pt_ctx* ctx, uint32_t slot, uint32_t* out, uint32_t n_ou
         out[0] = L.submitted ? 1u : 0u;
         out[1] = L.ready ? (uint32_t)hipStreamQuery(L.stream) : 0xFFFFFFFFu;
         out[2] = (uint32_t)L.frame_seq;
+        out[3] = L.last_schedule;
         if (!L.ready) return PT_OK;
         for (int k = 0; k < 2; ++k) {
             FrameSlot& sl = L.slot[k];

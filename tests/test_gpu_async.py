@@ -241,6 +241,30 @@ def test_frames_that_share_the_device_run_without_sample_sweeps():
         assert shared >= 3, shared
 
 
+def test_object_list_scenes_are_served_for_throughput_from_five_frames_in_flight():
+    """With few frames in flight the mesh of scene.glb has its BLAS in LDS (shorter chains); from five on the path
+    kernel runs without it (more workgroups per compute unit). pt_debug_slot_state tells which; the images are the same."""
+    scene = scenes.scene_glb_textured(1920, 1080, 16, 10)
+    times = [0.5 + k for k in range(8)]
+    with abi.Context() as ctx:
+        ctx.upload_scene(scene)
+        want = [ctx.render(scene.frame(time=t)) for t in times]
+        bufs = [ctx.host_array(want[0].shape, np.float32) for _ in range(8)]
+        for k_slots, deep in ((3, False), (8, True)):
+            for rep in range(3):     # (the first pass of a slot has no cost hints, and the BLAS goes into LDS only with them)
+                for s in range(k_slots):
+                    ctx.submit(scene.frame(time=times[s]), s, bufs[s])
+                for s in range(k_slots):
+                    ctx.wait(s)
+                    assert np.array_equal(bufs[s].view(np.uint32), want[s].view(np.uint32)), f"{k_slots} slots, pass {rep}, slot {s}"
+            how = [int(ctx.slot_state(s)[3]) for s in range(k_slots)]
+            assert all(h & 0x80000000 for h in how), how
+            last = how[k_slots - 1]                     # enqueued with every other slot in flight
+            assert ((last >> 8) & 15) == k_slots - 1, hex(last)
+            assert bool(last & 0x20) == deep, hex(last)
+            assert (last & 15) == (0 if deep else 3), hex(last)     # object list without / with a BLAS in LDS
+
+
 def test_gpu_side_ordering_of_a_slot_against_a_consumer_stream():
     """pt_render_stream_wait / pt_render_slot_wait_for: a consumer on a stream of its own (here: a slow chain of device copies
     that ends by saving the slot's image) reads every frame behind the frame and before the slot's next frame overwrites it,
