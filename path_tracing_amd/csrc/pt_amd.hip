@@ -197,7 +197,7 @@ struct pt_ctx {
     uint32_t max_sweeps = 3;      // see PathParams::n_sweeps
     uint32_t last_waves_needed = 0;   // the last frame that was ordered by cost hints: its work over its longest chunk, in waves (0: none yet)
     uint32_t deep_pipeline_slots = 4;   // frames of other slots in flight from which object-list scenes are served for throughput (PT_AMD_DEEP_PIPELINE; 0: always, 99: never)
-    uint32_t alone_streak = 0;    // consecutive submits on slots that found no frame of another slot waiting to be collected
+    uint32_t alone_streak = 0;    // consecutive submits on slots that found no frame of another slot still on the device
     bool sweeps_when_shared = false;   // PT_AMD_SWEEPS_SHARED=1: sample sweeps also for frames that run beside other frames (for measurements)
     std::vector<void*> host_allocs;  // page-locked host buffers handed out by pt_host_alloc
     bool queue_ahead = true;      // let the caller enqueue a frame while the previous one is still running
@@ -1457,11 +1457,19 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
                                              {k_paths<PT_MODE_LIST_LB, false>, k_paths<PT_MODE_LIST_LB, true>}};
         static const PathsFn ptable_roomy[4][2] = {{k_paths<PT_MODE_LIST, false, true>, k_paths<PT_MODE_LIST, true, true>}, {nullptr, nullptr}, {nullptr, nullptr},
                                                    {k_paths<PT_MODE_LIST_LB, false, true>, k_paths<PT_MODE_LIST_LB, true, true>}};
-        // Frames of other slots that wait to be collected as this one is enqueued: how deep the caller's pipeline is.
+        // Frames of other slots that are still on the device as this one is enqueued: how deep the caller's pipeline really
+        // is (a frame that has finished and only waits to be collected does not count: a caller who is paced by something
+        // else, a display say, may hold many of those while each of its frames has the device to itself).
         uint32_t n_others_pending = 0;
         if (!noalloc)
-            for (const Lane& o : ctx->lanes)   // (slots only: a synchronous frame stays "pending" until its statistics are read)
-                if (&o != &L && &o != &ctx->lanes[0] && o.ready && (o.slot[0].pending || o.slot[1].pending)) n_others_pending++;
+            for (const Lane& o : ctx->lanes) {   // (slots only: a synchronous frame stays "pending" until its statistics are read)
+                if (&o == &L || &o == &ctx->lanes[0] || !o.ready) continue;
+                bool running = false;
+                for (const FrameSlot& fs : o.slot)
+                    if (fs.pending && fs.ev1 && hipEventQuery(fs.ev1) == hipErrorNotReady) running = true;
+                if (running) n_others_pending++;
+            }
+        (void)hipGetLastError();   // (hipErrorNotReady is an answer, not an error to keep)
         // With five or more frames in flight an object-list scene is served for throughput: no BLAS in LDS and no chunks
         // in parts, both of which shorten a frame's longest chains at the price of workgroups per compute unit and idle
         // lanes -- the other frames' waves cover those chains instead (scene.glb with eight slots: 8.8 against 9.8 ms per
@@ -1530,7 +1538,7 @@ int render_enqueue(pt_ctx* ctx, Lane& L, const PtFrame* f, float* out, hipStream
         pp.sweep_end[0] = fp.samples;
         // Not for a frame that will run beside other frames (k_chunk_order has the reason). The kernel sees that for itself
         // when another frame of the process is running as it is scheduled; the host sees the caller's pattern earlier: a
-        // frame on a slot gets sweeps only when this and the last two submits found every other slot collected, so a caller
+        // frame on a slot gets sweeps only when this and the last two submits found no other slot's frame on the device, so a caller
         // that keeps frames in flight never has a frame with sweeps among them, the first frames included.
         bool beside_others = false;
         if (!noalloc) {
